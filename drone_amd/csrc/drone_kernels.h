@@ -1,0 +1,36 @@
+// drone_kernels.h — launch interface between the C-ABI host code
+// (drone_vec.cpp) and the gfx950 kernels (drone_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "drone_params.hpp"
+
+namespace drone {
+
+// Device pointers for one shard of envs.
+struct DeviceView {
+    float4* planes;      // [kNumPlanes][n_pad]
+    uint32_t n;          // envs on this device
+    uint32_t n_pad;      // plane stride (multiple of kBlock)
+    const uint32_t* kp;  // KParams in HBM (kParamWords words) — staged to LDS per workgroup
+    float* obs;          // [n][20]
+    const float* act;    // [n][4]
+    float* rew;          // [n]
+    unsigned char* term; // [n]
+    unsigned char* trunc;// [n]
+    uint32_t* done_ids;  // [n] or null
+    uint32_t* done_count;// [2] ping-pong by gstep parity, or null
+};
+
+constexpr int kBlock = 256;
+
+hipError_t launch_reset(const DeviceView& v, hipStream_t s);
+hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s);
+hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s);
+hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s);
+// partials: [grid][6] doubles; returns grid size via *grid_out. Clears the log planes.
+hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid, int* grid_out, hipStream_t s);
+
+}  // namespace drone

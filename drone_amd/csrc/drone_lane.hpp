@@ -1,0 +1,273 @@
+// drone_lane.hpp — what ONE lane does for ONE drone, entirely in registers:
+// rotor model, RK4 Newton–Euler integration, bounds, reward, episodic reset,
+// observation. Implements SPEC.md §4–§7 (BASELINE.json north_star stages
+// a2–a7; the reference has no source to cite — /root/reference/.gitmodules:1-3).
+//
+// Numerics contract: compiled with -ffp-contract=off; the only fused
+// operations are the fma() calls below, `/` and sqrtf are correctly rounded
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), no transcendental
+// calls. That is what makes the result bit-identical to the scalar CPU oracle.
+//
+// `P` is a reference to the KParams block; in the kernels it lives in LDS.
+#pragma once
+
+#include "drone_params.hpp"
+
+namespace drone {
+
+#define fma_(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// the 17 integrated components
+struct Dyn {
+    float p[3], v[3], q[4], o[3], r[4];
+};
+
+struct Lane {
+    Dyn s;
+    float tgt[3];
+    float wind[3];
+    float ep_return;
+    uint32_t tick, episode, score_count;
+};
+
+struct StepOut {
+    float reward;
+    bool oob, trunc;
+    bool target_changed;  // target plane must be written back
+    // valid when oob || trunc: this episode's contribution to the log sums
+    float perf, score, ep_return, ep_len;
+};
+
+DRONE_FN float clampc(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+template <int TASK>
+DRONE_FN void deriv(const KParams& P, const Dyn& S, const float (&cmd)[4], const float (&wind)[3], Dyn& D) {
+    const float w = S.q[0], x = S.q[1], y = S.q[2], z = S.q[3];
+    const float ox = S.o[0], oy = S.o[1], oz = S.o[2];
+    const float q0 = S.r[0] * S.r[0], q1 = S.r[1] * S.r[1], q2 = S.r[2] * S.r[2], q3 = S.r[3] * S.r[3];
+    const float f0 = P.k_thrust * q0, f1 = P.k_thrust * q1, f2 = P.k_thrust * q2, f3 = P.k_thrust * q3;
+    const float f01 = f0 + f1, f23 = f2 + f3;
+    const float T = f01 + f23;
+    const float tx = P.arm_xy * (f01 - f23);
+    const float ty = P.arm_xy * ((f1 + f2) - (f0 + f3));
+    const float tz = P.k_torque * ((q0 + q2) - (q1 + q3));
+    const float zx = 2.0f * fma_(x, z, w * y);
+    const float zy = 2.0f * fma_(y, z, -(w * x));
+    const float zz = fma_(-2.0f, fma_(x, x, y * y), 1.0f);
+    const float aT = T * P.inv_mass;
+    if (TASK == DRONE_TASK_WAYPOINT) {
+        D.v[0] = fma_(aT, zx, -(P.drag_m * (S.v[0] - wind[0])));
+        D.v[1] = fma_(aT, zy, -(P.drag_m * (S.v[1] - wind[1])));
+        D.v[2] = fma_(aT, zz, -P.gravity) - P.drag_m * (S.v[2] - wind[2]);
+    } else {  // wind == 0 and v - 0 is exact (SPEC.md §4)
+        D.v[0] = fma_(aT, zx, -(P.drag_m * S.v[0]));
+        D.v[1] = fma_(aT, zy, -(P.drag_m * S.v[1]));
+        D.v[2] = fma_(aT, zz, -P.gravity) - P.drag_m * S.v[2];
+    }
+    D.o[0] = P.inv_ixx * ((tx - P.gx * (oy * oz)) - P.k_ang_damp * ox);
+    D.o[1] = P.inv_iyy * ((ty - P.gy * (oz * ox)) - P.k_ang_damp * oy);
+    D.o[2] = P.inv_izz * ((tz - P.gz * (ox * oy)) - P.k_ang_damp * oz);
+    D.q[0] = -0.5f * fma_(x, ox, fma_(y, oy, z * oz));
+    D.q[1] = 0.5f * fma_(w, ox, fma_(y, oz, -(z * oy)));
+    D.q[2] = 0.5f * fma_(w, oy, fma_(z, ox, -(x * oz)));
+    D.q[3] = 0.5f * fma_(w, oz, fma_(x, oy, -(y * ox)));
+#pragma unroll
+    for (int i = 0; i < 4; i++) D.r[i] = (cmd[i] - S.r[i]) * P.inv_tau;
+#pragma unroll
+    for (int i = 0; i < 3; i++) D.p[i] = S.v[i];
+}
+
+// acc/A update for every component; `first` selects acc = k vs acc = fma(2,k,acc)
+#define DRONE_FOR_COMPONENTS(BODY)                       \
+    _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(p, i) } \
+    _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(v, i) } \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) { BODY(q, i) } \
+    _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(o, i) } \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) { BODY(r, i) }
+
+template <int TASK>
+DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3]) {
+    Dyn k, A, acc;
+    const float h = P.h, hh = P.h_half, h6 = P.h_sixth;
+    deriv<TASK>(P, S, cmd, wind, k);
+#define STAGE1(f, i) acc.f[i] = k.f[i]; A.f[i] = fma_(hh, k.f[i], S.f[i]);
+    DRONE_FOR_COMPONENTS(STAGE1)
+    deriv<TASK>(P, A, cmd, wind, k);
+#define STAGE2(f, i) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(hh, k.f[i], S.f[i]);
+    DRONE_FOR_COMPONENTS(STAGE2)
+    deriv<TASK>(P, A, cmd, wind, k);
+#define STAGE3(f, i) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(h, k.f[i], S.f[i]);
+    DRONE_FOR_COMPONENTS(STAGE3)
+    deriv<TASK>(P, A, cmd, wind, k);
+#define STAGE4(f, i) acc.f[i] = acc.f[i] + k.f[i]; S.f[i] = fma_(h6, acc.f[i], S.f[i]);
+    DRONE_FOR_COMPONENTS(STAGE4)
+#undef STAGE1
+#undef STAGE2
+#undef STAGE3
+#undef STAGE4
+}
+
+DRONE_FN float target_dist(const Lane& L) {
+    const float dx = L.tgt[0] - L.s.p[0], dy = L.tgt[1] - L.s.p[1], dz = L.tgt[2] - L.s.p[2];
+    return sqrtf(fma_(dx, dx, fma_(dy, dy, dz * dz)));
+}
+
+// SPEC.md §6. `env` is the global env id.
+DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
+    const uint32_t b = rng_base(P.key_reset, env, L.episode);
+    float t[3];
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++) {
+        L.s.p[i] = P.spawn_extent * sym(rng_draw(b, i));
+        L.tgt[i] = P.target_extent * sym(rng_draw(b, 3u + i));
+        t[i] = P.tilt_init * sym(rng_draw(b, 6u + i));
+    }
+    const float n2 = fma_(t[0], t[0], fma_(t[1], t[1], fma_(t[2], t[2], 1.0f)));
+    const float inv = 1.0f / sqrtf(n2);
+    L.s.q[0] = inv;
+    L.s.q[1] = t[0] * inv;
+    L.s.q[2] = t[1] * inv;
+    L.s.q[3] = t[2] * inv;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        L.s.v[i] = 0.0f;
+        L.s.o[i] = 0.0f;
+        L.wind[i] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) L.s.r[i] = P.hover_rpm;
+    L.tick = 0;
+    L.score_count = 0;
+    L.ep_return = 0.0f;
+}
+
+// SPEC.md §2: the synthetic random policy.
+DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float (&a)[4]) {
+    const uint32_t b = rng_base(key_action, env, gstep);
+    const uint32_t h0 = rng_draw(b, 0u), h1 = rng_draw(b, 1u);
+    a[0] = s16(h0 & 0xFFFFu);
+    a[1] = s16(h0 >> 16);
+    a[2] = s16(h1 & 0xFFFFu);
+    a[3] = s16(h1 >> 16);
+}
+
+// SPEC.md §5 steps 1–9 (everything but the observation).
+template <int TASK>
+DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
+    float a[4], cmd[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[i] = clampc(act[i], -1.0f, 1.0f);
+        cmd[i] = P.half_max_rpm * (a[i] + 1.0f);
+    }
+    float prev_dist = 0.0f;
+    if (TASK == DRONE_TASK_WAYPOINT) {
+        const uint32_t b = rng_base(P.key_wind, env, gstep);
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {
+            const uint32_t u = rng_draw(b, i);
+            const uint32_t sum = (u & 255u) + ((u >> 8) & 255u) + ((u >> 16) & 255u) + (u >> 24);
+            const float xi = (float)((int)sum - 510);
+            L.wind[i] = clampc(fma_(P.wind_decay, L.wind[i], P.wind_gain * xi), -P.wind_max, P.wind_max);
+        }
+        prev_dist = target_dist(L);
+    }
+
+    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind);
+
+    {
+        float* q = L.s.q;
+        const float n2 = fma_(q[0], q[0], fma_(q[1], q[1], fma_(q[2], q[2], q[3] * q[3])));
+        const float inv = 1.0f / sqrtf(n2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = q[i] * inv;
+#pragma unroll
+        for (int i = 0; i < 3; i++) L.s.v[i] = clampc(L.s.v[i], -P.max_vel, P.max_vel);
+#pragma unroll
+        for (int i = 0; i < 3; i++) L.s.o[i] = clampc(L.s.o[i], -P.max_omega, P.max_omega);
+#pragma unroll
+        for (int i = 0; i < 4; i++) L.s.r[i] = clampc(L.s.r[i], 0.0f, P.max_rpm);
+    }
+    L.tick += 1u;
+
+    const float dist = target_dist(L);
+    const bool oob = !(fabsf(L.s.p[0]) <= P.bound) || !(fabsf(L.s.p[1]) <= P.bound) || !(fabsf(L.s.p[2]) <= P.bound);
+    const bool trunc = !oob && L.tick >= P.horizon;
+
+    const float w2 = fma_(L.s.o[0], L.s.o[0], fma_(L.s.o[1], L.s.o[1], L.s.o[2] * L.s.o[2]));
+    const float a2 = fma_(a[0], a[0], fma_(a[1], a[1], fma_(a[2], a[2], a[3] * a[3])));
+    const float pen = fma_(P.c_omega, w2, P.c_action * a2);
+    float r;
+    bool target_changed = false;
+    if (TASK == DRONE_TASK_HOVER) {
+        r = 1.0f / (1.0f + dist) - pen;
+        if (dist < P.hover_radius) L.score_count += 1u;
+    } else {
+        r = P.progress_scale * (prev_dist - dist) - pen;
+        if (!oob && dist < P.waypoint_radius) {
+            r += P.waypoint_bonus;
+            L.score_count += 1u;
+            const uint32_t b = rng_base(P.key_waypoint, env, L.episode);
+#pragma unroll
+            for (uint32_t i = 0; i < 3; i++) L.tgt[i] = P.target_extent * sym(rng_draw(b, 3u * L.score_count + i));
+            target_changed = true;
+        }
+    }
+    if (oob) r -= P.crash_penalty;
+    L.ep_return += r;
+
+    out.reward = r;
+    out.oob = oob;
+    out.trunc = trunc;
+    out.perf = out.score = out.ep_return = out.ep_len = 0.0f;
+    if (oob || trunc) {
+        float score, perf;
+        if (TASK == DRONE_TASK_HOVER) {
+            score = (float)L.score_count / (float)L.tick;
+            perf = score;
+        } else {
+            score = (float)L.score_count;
+            perf = L.score_count >= 8u ? 1.0f : (float)L.score_count * 0.125f;
+        }
+        out.perf = perf;
+        out.score = score;
+        out.ep_return = L.ep_return;
+        out.ep_len = (float)L.tick;
+        L.episode += 1u;
+        lane_reset(P, L, env);
+        target_changed = true;
+    }
+    out.target_changed = target_changed;
+}
+
+// SPEC.md §7
+DRONE_FN void lane_obs(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM]) {
+    const float w = L.s.q[0], x = L.s.q[1], y = L.s.q[2], z = L.s.q[3];
+    const float r00 = fma_(-2.0f, fma_(y, y, z * z), 1.0f);
+    const float r01 = 2.0f * fma_(x, y, -(w * z));
+    const float r02 = 2.0f * fma_(x, z, w * y);
+    const float r10 = 2.0f * fma_(x, y, w * z);
+    const float r11 = fma_(-2.0f, fma_(x, x, z * z), 1.0f);
+    const float r12 = 2.0f * fma_(y, z, -(w * x));
+    const float r20 = 2.0f * fma_(x, z, -(w * y));
+    const float r21 = 2.0f * fma_(y, z, w * x);
+    const float r22 = fma_(-2.0f, fma_(x, x, y * y), 1.0f);
+    const float vx = L.s.v[0], vy = L.s.v[1], vz = L.s.v[2];
+    o[0] = fma_(r00, vx, fma_(r10, vy, r20 * vz)) * P.inv_max_vel;
+    o[1] = fma_(r01, vx, fma_(r11, vy, r21 * vz)) * P.inv_max_vel;
+    o[2] = fma_(r02, vx, fma_(r12, vy, r22 * vz)) * P.inv_max_vel;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[3 + i] = L.s.o[i] * P.inv_max_omega;
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[6 + i] = L.s.q[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[10 + i] = L.s.r[i] * P.inv_max_rpm;
+    const float ex = L.tgt[0] - L.s.p[0], ey = L.tgt[1] - L.s.p[1], ez = L.tgt[2] - L.s.p[2];
+    o[14] = fma_(r00, ex, fma_(r10, ey, r20 * ez)) * P.half_inv_bound;
+    o[15] = fma_(r01, ex, fma_(r11, ey, r21 * ez)) * P.half_inv_bound;
+    o[16] = fma_(r02, ex, fma_(r12, ey, r22 * ez)) * P.half_inv_bound;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[17 + i] = L.s.p[i] * P.inv_bound;
+}
+
+}  // namespace drone

@@ -1,0 +1,138 @@
+// drone_params.hpp — constants block staged into LDS by every kernel, the
+// counter RNG, and the plane layout of the device state.
+//
+// Follows SPEC.md §1–§3 (this repo's spec; the reference has no source to
+// cite — /root/reference/.gitmodules:1-3). Written
+// independently of oracle/: nothing here includes or links the oracle.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/drone_vec.h"
+
+#if defined(__HIPCC__)
+#define DRONE_FN __device__ __host__ __forceinline__
+#else
+#define DRONE_FN static inline __attribute__((always_inline))
+#endif
+
+namespace drone {
+
+enum Stream : uint32_t { kReset = 0, kAction = 1, kWind = 2, kWaypoint = 3 };
+
+// ---- device state: float4 planes, each [n_pad] (DESIGN.md "Data layout") ----
+// One lane reads/writes one float4 per plane: 16 B/lane, 1 KiB per
+// wave-instruction, fully coalesced.
+enum Plane : int {
+    kP0 = 0,    // pos.x pos.y pos.z vel.x
+    kP1 = 1,    // vel.y vel.z q.w q.x
+    kP2 = 2,    // q.y q.z om.x om.y
+    kP3 = 3,    // om.z rpm0 rpm1 rpm2
+    kP4 = 4,    // rpm3 ep_return tick(u32) score_count(u32)
+    kPT = 5,    // target.x target.y target.z episode(u32)   — written only when it changes
+    kPW = 6,    // wind.x wind.y wind.z (pad)               — task 1 only
+    kL0 = 7,    // perf_sum score_sum ret_sum len_sum        — touched only when an episode ends
+    kL1 = 8,    // n_sum oob_sum (pad) (pad)
+    kNumPlanes = 9
+};
+
+// Everything a lane needs that is the same for all lanes. 48 words; each
+// workgroup copies it from HBM into LDS once and lanes read it by broadcast
+// ds_read (no bank conflicts: all lanes hit the same address).
+struct KParams {
+    // integrator / dynamics
+    float h, h_half, h_sixth;
+    float inv_mass, inv_ixx, inv_iyy, inv_izz;
+    float gx, gy, gz;
+    float arm_xy, drag_m, inv_tau;
+    float k_thrust, k_torque, k_ang_damp, gravity;
+    float half_max_rpm, hover_rpm, max_rpm, max_vel, max_omega;
+    // observation scales
+    float inv_max_vel, inv_max_omega, inv_max_rpm, inv_bound, half_inv_bound;
+    // task
+    float bound, spawn_extent, target_extent, tilt_init;
+    float hover_radius, waypoint_radius;
+    float wind_decay, wind_gain, wind_max;
+    float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
+    // integers
+    uint32_t horizon, substeps;
+    uint32_t key_reset, key_action, key_wind, key_waypoint;
+    uint32_t env_offset;
+};
+static_assert(sizeof(KParams) == 48 * 4, "KParams is staged as 48 words");
+constexpr int kParamWords = 48;
+
+// ---- SPEC.md §2: counter RNG ----
+DRONE_FN uint32_t hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+DRONE_FN uint32_t rng_base(uint32_t key, uint32_t env, uint32_t ctr) {
+    return hash32(hash32(key ^ env) + ctr * 0x9E3779B9u);
+}
+DRONE_FN uint32_t rng_draw(uint32_t base, uint32_t d) { return hash32(base + d * 0x85EBCA6Bu); }
+DRONE_FN float sym(uint32_t u) { return __builtin_fmaf(2.0f, (float)(u >> 8) * 5.9604645e-8f, -1.0f); }
+DRONE_FN float s16(uint32_t h) { return (float)((int)h - 32768) * 3.0517578125e-5f; }
+
+inline uint32_t stream_key(uint64_t seed, uint32_t stream) {
+    return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) ^ (0x9E3779B9u * (stream + 1u))));
+}
+
+// ---- SPEC.md §1: derived parameters (host, float, fixed order) ----
+inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
+    p.h = c.dt / (float)c.substeps;
+    p.h_half = 0.5f * p.h;
+    p.h_sixth = p.h / 6.0f;
+    p.inv_mass = 1.0f / c.mass;
+    p.inv_ixx = 1.0f / c.ixx;
+    p.inv_iyy = 1.0f / c.iyy;
+    p.inv_izz = 1.0f / c.izz;
+    p.gx = c.izz - c.iyy;
+    p.gy = c.ixx - c.izz;
+    p.gz = c.iyy - c.ixx;
+    p.arm_xy = c.arm * 0.70710678f;
+    p.drag_m = c.k_drag * p.inv_mass;
+    p.inv_tau = 1.0f / c.motor_tau;
+    p.k_thrust = c.k_thrust;
+    p.k_torque = c.k_torque;
+    p.k_ang_damp = c.k_ang_damp;
+    p.gravity = c.gravity;
+    p.half_max_rpm = 0.5f * c.max_rpm;
+    p.hover_rpm = sqrtf((c.mass * c.gravity) / (4.0f * c.k_thrust));
+    p.max_rpm = c.max_rpm;
+    p.max_vel = c.max_vel;
+    p.max_omega = c.max_omega;
+    p.inv_max_vel = 1.0f / c.max_vel;
+    p.inv_max_omega = 1.0f / c.max_omega;
+    p.inv_max_rpm = 1.0f / c.max_rpm;
+    p.inv_bound = 1.0f / c.bound;
+    p.half_inv_bound = 0.5f * p.inv_bound;
+    p.bound = c.bound;
+    p.spawn_extent = c.spawn_extent;
+    p.target_extent = c.target_extent;
+    p.tilt_init = c.tilt_init;
+    p.hover_radius = c.hover_radius;
+    p.waypoint_radius = c.waypoint_radius;
+    p.wind_decay = 1.0f - c.wind_theta * c.dt;
+    p.wind_gain = (c.wind_sigma * sqrtf(c.dt)) * 0.0067658754f;
+    p.wind_max = c.wind_max;
+    p.c_omega = c.c_omega;
+    p.c_action = c.c_action;
+    p.crash_penalty = c.crash_penalty;
+    p.progress_scale = c.progress_scale;
+    p.waypoint_bonus = c.waypoint_bonus;
+    p.horizon = (uint32_t)c.horizon;
+    p.substeps = (uint32_t)c.substeps;
+    p.key_reset = stream_key(seed, kReset);
+    p.key_action = stream_key(seed, kAction);
+    p.key_wind = stream_key(seed, kWind);
+    p.key_waypoint = stream_key(seed, kWaypoint);
+    p.env_offset = c.env_offset;
+}
+
+}  // namespace drone

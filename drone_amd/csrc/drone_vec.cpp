@@ -1,0 +1,441 @@
+// drone_vec.cpp — host side of the C-ABI in include/drone_vec.h.
+//
+// Owns the device state planes, the KParams block, the stream and (in
+// host-buffer mode) the device mirrors of the caller's buffers. Every entry
+// point ends in a HIP launch from drone_kernels.hip: there is no CPU
+// implementation of the env in this library, and it fails loudly (NULL /
+// non-zero + drone_last_error()) when HIP or the device is unavailable.
+//
+// Replaces, on the PufferLib side, the binding's vec_init / vec_reset /
+// vec_step / vec_log / vec_close loop over per-env c_step; the
+// reference file:line cannot be cited — no source in /root/reference
+// (.gitmodules:1-3).
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "drone_kernels.h"
+
+using namespace drone;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr, onfail)                                                        \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            onfail;                                                                  \
+        }                                                                            \
+    } while (0)
+
+constexpr int kLogMaxGrid = 1024;
+
+}  // namespace
+
+struct DroneVec {
+    DroneConfig cfg;
+    KParams kp;
+    uint64_t seed;
+    uint32_t gstep;
+    int n;
+    uint32_t n_pad;
+    int device;
+    bool host_buffers;
+    // caller buffers (host or device, per cfg.buffer_kind)
+    float* u_obs;
+    float* u_act;
+    float* u_rew;
+    unsigned char* u_term;
+    unsigned char* u_trunc;
+    bool registered[5];
+    // device side
+    DeviceView dv;
+    uint32_t* d_kp;
+    double* d_partials;
+    double* h_partials;  // pinned
+    float* d_obs;        // device mirrors (host-buffer mode only)
+    float* d_act;
+    float* d_rew;
+    unsigned char* d_term;
+    unsigned char* d_trunc;
+    hipStream_t stream;
+    bool own_stream;
+    hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+bool set_device(const DroneVec* v) {
+    HIP_TRY(hipSetDevice(v->device), return false);
+    return true;
+}
+
+bool upload_params(DroneVec* v) {
+    derive_kparams(v->cfg, v->seed, v->kp);
+    HIP_TRY(hipMemcpyAsync(v->d_kp, &v->kp, sizeof(KParams), hipMemcpyHostToDevice, v->stream), return false);
+    // the source is the handle's own field; make the copy complete before it can change again
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);
+    return true;
+}
+
+bool validate(const DroneConfig* c, int num_envs) {
+    if (!c) { set_err("config is NULL"); return false; }
+    if (c->struct_size != sizeof(DroneConfig)) { set_err("DroneConfig.struct_size %u != %zu", c->struct_size, sizeof(DroneConfig)); return false; }
+    if (num_envs <= 0) { set_err("num_envs must be positive"); return false; }
+    if (c->task != DRONE_TASK_HOVER && c->task != DRONE_TASK_WAYPOINT) { set_err("unknown task %d", c->task); return false; }
+    if (c->buffer_kind != DRONE_BUFFERS_HOST && c->buffer_kind != DRONE_BUFFERS_DEVICE) { set_err("unknown buffer_kind %d", c->buffer_kind); return false; }
+    if (c->substeps < 1 || c->horizon < 1) { set_err("substeps and horizon must be >= 1"); return false; }
+    if (!(c->dt > 0.0f) || !(c->mass > 0.0f) || !(c->ixx > 0.0f) || !(c->iyy > 0.0f) || !(c->izz > 0.0f) || !(c->motor_tau > 0.0f) ||
+        !(c->max_rpm > 0.0f) || !(c->max_vel > 0.0f) || !(c->max_omega > 0.0f) || !(c->bound > 0.0f) || !(c->k_thrust > 0.0f)) {
+        set_err("physical constants must be positive");
+        return false;
+    }
+    return true;
+}
+
+bool host_to_device_actions(DroneVec* v) {
+    HIP_TRY(hipMemcpyAsync(v->d_act, v->u_act, (size_t)v->n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return false);
+    return true;
+}
+
+bool device_to_host_outputs(DroneVec* v) {
+    const size_t n = (size_t)v->n;
+    HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * DRONE_OBS_DIM * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_rew, v->d_rew, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_term, v->d_term, n, hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_trunc, v->d_trunc, n, hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);
+    return true;
+}
+
+void try_register(DroneVec* v, int slot, void* p, size_t bytes) {
+    // Pin the caller's pages so the per-step copies are true async DMA. Not
+    // fatal if it fails (already pinned, or not page-lockable): pageable copies still work.
+    v->registered[slot] = (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess);
+    if (!v->registered[slot]) (void)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* drone_last_error(void) { return g_err; }
+
+void drone_config_default(DroneConfig* c, int task) {
+    memset(c, 0, sizeof(*c));
+    c->struct_size = (uint32_t)sizeof(DroneConfig);
+    c->task = task;
+    c->buffer_kind = DRONE_BUFFERS_HOST;
+    c->horizon = 1024;
+    c->substeps = 1;
+    c->dt = 0.01f;
+    // Crazyflie-2.x-class airframe (public datasheet-level numbers)
+    c->mass = 0.027f;
+    c->arm = 0.0397f;
+    c->ixx = 1.4e-5f;
+    c->iyy = 1.4e-5f;
+    c->izz = 2.17e-5f;
+    c->k_thrust = 3.16e-10f;
+    c->k_torque = 7.94e-12f;
+    c->k_drag = 0.0027f;
+    c->k_ang_damp = 1.0e-6f;
+    c->gravity = 9.81f;
+    c->max_rpm = 21702.0f;
+    c->motor_tau = 0.05f;
+    c->max_vel = 20.0f;
+    c->max_omega = 50.0f;
+    c->bound = 5.0f;
+    c->spawn_extent = 3.0f;
+    c->target_extent = 3.0f;
+    c->tilt_init = 0.1f;
+    c->hover_radius = 0.5f;
+    c->waypoint_radius = 0.5f;
+    c->wind_theta = 0.5f;
+    c->wind_sigma = 1.0f;
+    c->wind_max = 5.0f;
+    c->c_omega = 1.0e-4f;
+    c->c_action = 0.01f;
+    c->crash_penalty = 1.0f;
+    c->progress_scale = 1.0f;
+    c->waypoint_bonus = 1.0f;
+}
+
+DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, unsigned char* terminals,
+                         unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {
+    g_err[0] = 0;
+    if (!validate(cfg, num_envs)) return nullptr;
+    if (!observations || !actions || !rewards || !terminals || !truncations) { set_err("buffer pointer is NULL"); return nullptr; }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev), return nullptr);
+    if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set_err("HIP device %d not available (%d devices): this library has no CPU path", cfg->device, ndev); return nullptr; }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device), return nullptr);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_err("device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName); return nullptr; }
+
+    DroneVec* v = new (std::nothrow) DroneVec();
+    if (!v) { set_err("out of memory"); return nullptr; }
+    memset(v, 0, sizeof(*v));
+    v->cfg = *cfg;
+    v->seed = seed;
+    v->n = num_envs;
+    v->n_pad = (uint32_t)((num_envs + kBlock - 1) / kBlock) * kBlock;
+    v->device = cfg->device;
+    v->host_buffers = cfg->buffer_kind == DRONE_BUFFERS_HOST;
+    v->u_obs = observations; v->u_act = actions; v->u_rew = rewards; v->u_term = terminals; v->u_trunc = truncations;
+
+    const size_t n = (size_t)num_envs;
+#define INIT_TRY(expr) HIP_TRY(expr, { drone_vec_close(v); return nullptr; })
+    INIT_TRY(hipSetDevice(v->device));
+    INIT_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    v->own_stream = true;
+    INIT_TRY(hipEventCreate(&v->ev0));
+    INIT_TRY(hipEventCreate(&v->ev1));
+    INIT_TRY(hipMalloc((void**)&v->dv.planes, sizeof(float4) * (size_t)kNumPlanes * v->n_pad));
+    INIT_TRY(hipMemsetAsync(v->dv.planes, 0, sizeof(float4) * (size_t)kNumPlanes * v->n_pad, v->stream));
+    INIT_TRY(hipMalloc((void**)&v->d_kp, sizeof(KParams)));
+    INIT_TRY(hipMalloc((void**)&v->d_partials, sizeof(double) * 6 * kLogMaxGrid));
+    INIT_TRY(hipHostMalloc((void**)&v->h_partials, sizeof(double) * 6 * kLogMaxGrid, hipHostMallocDefault));
+    if (cfg->compact_done) {
+        INIT_TRY(hipMalloc((void**)&v->dv.done_ids, sizeof(uint32_t) * n));
+        INIT_TRY(hipMalloc((void**)&v->dv.done_count, sizeof(uint32_t) * 2));
+        INIT_TRY(hipMemsetAsync(v->dv.done_count, 0, sizeof(uint32_t) * 2, v->stream));
+    }
+    if (v->host_buffers) {
+        INIT_TRY(hipMalloc((void**)&v->d_obs, n * DRONE_OBS_DIM * sizeof(float)));
+        INIT_TRY(hipMalloc((void**)&v->d_act, n * DRONE_ACT_DIM * sizeof(float)));
+        INIT_TRY(hipMalloc((void**)&v->d_rew, n * sizeof(float)));
+        INIT_TRY(hipMalloc((void**)&v->d_term, n));
+        INIT_TRY(hipMalloc((void**)&v->d_trunc, n));
+        try_register(v, 0, observations, n * DRONE_OBS_DIM * sizeof(float));
+        try_register(v, 1, actions, n * DRONE_ACT_DIM * sizeof(float));
+        try_register(v, 2, rewards, n * sizeof(float));
+        try_register(v, 3, terminals, n);
+        try_register(v, 4, truncations, n);
+        v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
+    } else {
+        if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
+            set_err("device buffers must be 16-byte aligned (observations, actions) and 4-byte aligned (rewards)");
+            drone_vec_close(v);
+            return nullptr;
+        }
+        v->dv.obs = observations; v->dv.act = actions; v->dv.rew = rewards; v->dv.term = terminals; v->dv.trunc = truncations;
+    }
+    v->dv.n = (uint32_t)num_envs;
+    v->dv.n_pad = v->n_pad;
+    v->dv.kp = v->d_kp;
+    if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
+#undef INIT_TRY
+    return v;
+}
+
+void drone_vec_reset(DroneVec* v, uint64_t seed) {
+    if (!v || !set_device(v)) return;
+    v->seed = seed;
+    v->gstep = 0;
+    if (!upload_params(v)) return;
+    HIP_TRY(launch_reset(v->dv, v->stream), return);
+    if (v->host_buffers) device_to_host_outputs(v);
+}
+
+void drone_vec_step(DroneVec* v) {
+    if (!v || !set_device(v)) return;
+    if (v->host_buffers && !host_to_device_actions(v)) return;
+    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->stream), return);
+    v->gstep += 1;
+    if (v->host_buffers) device_to_host_outputs(v);
+}
+
+void drone_vec_rollout(DroneVec* v, int horizon) {
+    if (!v || horizon <= 0 || !set_device(v)) return;
+    HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream), return);
+    v->gstep += (uint32_t)horizon;
+    if (v->host_buffers) device_to_host_outputs(v);
+}
+
+void drone_vec_log(DroneVec* v, DroneLog* out) {
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    if (!v || !set_device(v)) return;
+    int grid = 0;
+    HIP_TRY(launch_log_reduce(v->dv, v->d_partials, kLogMaxGrid, &grid, v->stream), return);
+    HIP_TRY(hipMemcpyAsync(v->h_partials, v->d_partials, sizeof(double) * 6 * grid, hipMemcpyDeviceToHost, v->stream), return);
+    HIP_TRY(hipStreamSynchronize(v->stream), return);
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < grid; b++)
+        for (int k = 0; k < 6; k++) s[k] += v->h_partials[b * 6 + k];
+    const double n = s[4];
+    if (n > 0) {
+        out->perf = (float)(s[0] / n);
+        out->score = (float)(s[1] / n);
+        out->episode_return = (float)(s[2] / n);
+        out->episode_length = (float)(s[3] / n);
+        out->oob = (float)(s[5] / n);
+    }
+    out->n = (float)n;
+}
+
+void drone_vec_close(DroneVec* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    if (v->stream) (void)hipStreamSynchronize(v->stream);
+    void* regs[5] = {v->u_obs, v->u_act, v->u_rew, v->u_term, v->u_trunc};
+    for (int i = 0; i < 5; i++)
+        if (v->registered[i]) (void)hipHostUnregister(regs[i]);
+    (void)hipFree(v->dv.planes);
+    (void)hipFree(v->d_kp);
+    (void)hipFree(v->d_partials);
+    if (v->h_partials) (void)hipHostFree(v->h_partials);
+    (void)hipFree(v->dv.done_ids);
+    (void)hipFree(v->dv.done_count);
+    (void)hipFree(v->d_obs);
+    (void)hipFree(v->d_act);
+    (void)hipFree(v->d_rew);
+    (void)hipFree(v->d_term);
+    (void)hipFree(v->d_trunc);
+    if (v->ev0) (void)hipEventDestroy(v->ev0);
+    if (v->ev1) (void)hipEventDestroy(v->ev1);
+    if (v->own_stream && v->stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+}
+
+int drone_vec_set_stream(DroneVec* v, void* hip_stream) {
+    if (!v) return -1;
+    if (!set_device(v)) return -1;
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    if (v->own_stream && v->stream) (void)hipStreamDestroy(v->stream);
+    v->stream = (hipStream_t)hip_stream;
+    v->own_stream = false;
+    return 0;
+}
+
+int drone_vec_sync(DroneVec* v) {
+    if (!v) return -1;
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    return 0;
+}
+
+int drone_vec_bind_actions(DroneVec* v, float* actions) {
+    if (!v || !actions) return -1;
+    if (v->host_buffers) {
+        v->u_act = actions;  // copied (pageable unless the caller pinned it) at the next step
+    } else {
+        if (reinterpret_cast<uintptr_t>(actions) & 15u) { set_err("actions must be 16-byte aligned"); return -1; }
+        v->u_act = actions;
+        v->dv.act = actions;
+    }
+    return 0;
+}
+
+int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep) {
+    if (!v || !actions) return -1;
+    if (!set_device(v)) return -1;
+    if (v->host_buffers) {
+        // generate on the device into the action mirror, then hand the host its copy
+        HIP_TRY(launch_fill_actions(v->dv, v->d_act, gstep, v->stream), return -1);
+        HIP_TRY(hipMemcpyAsync(actions, v->d_act, (size_t)v->n * DRONE_ACT_DIM * sizeof(float), hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    } else {
+        if (reinterpret_cast<uintptr_t>(actions) & 15u) { set_err("actions must be 16-byte aligned"); return -1; }
+        HIP_TRY(launch_fill_actions(v->dv, actions, gstep, v->stream), return -1);
+    }
+    return 0;
+}
+
+uint32_t drone_vec_gstep(const DroneVec* v) { return v ? v->gstep : 0u; }
+int drone_vec_num_envs(const DroneVec* v) { return v ? v->n : 0; }
+
+// ---- AoS import / export (tests, checkpoints): plain copies + host repack ----
+int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) {
+    if (!v || !rows || first < 0 || count < 0 || first + count > v->n) { set_err("get_state: bad range"); return -1; }
+    if (!set_device(v)) return -1;
+    std::vector<float4> tmp((size_t)kNumPlanes * count);
+    for (int p = 0; p < kNumPlanes; p++)
+        HIP_TRY(hipMemcpyAsync(tmp.data() + (size_t)p * count, v->dv.planes + (size_t)p * v->n_pad + first, sizeof(float4) * count, hipMemcpyDeviceToHost, v->stream), return -1);
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    auto u = [](float f) { uint32_t x; memcpy(&x, &f, 4); return x; };
+    for (int i = 0; i < count; i++) {
+        const float4 a = tmp[(size_t)kP0 * count + i], b = tmp[(size_t)kP1 * count + i], c = tmp[(size_t)kP2 * count + i];
+        const float4 d = tmp[(size_t)kP3 * count + i], e = tmp[(size_t)kP4 * count + i], t = tmp[(size_t)kPT * count + i];
+        const float4 w = tmp[(size_t)kPW * count + i], l0 = tmp[(size_t)kL0 * count + i], l1 = tmp[(size_t)kL1 * count + i];
+        DroneStateRow& r = rows[i];
+        r.pos[0] = a.x; r.pos[1] = a.y; r.pos[2] = a.z; r.vel[0] = a.w;
+        r.vel[1] = b.x; r.vel[2] = b.y; r.quat[0] = b.z; r.quat[1] = b.w;
+        r.quat[2] = c.x; r.quat[3] = c.y; r.omega[0] = c.z; r.omega[1] = c.w;
+        r.omega[2] = d.x; r.rpm[0] = d.y; r.rpm[1] = d.z; r.rpm[2] = d.w;
+        r.rpm[3] = e.x; r.ep_return = e.y; r.tick = u(e.z); r.score_count = u(e.w);
+        r.target[0] = t.x; r.target[1] = t.y; r.target[2] = t.z; r.episode = u(t.w);
+        r.wind[0] = w.x; r.wind[1] = w.y; r.wind[2] = w.z;
+        r.perf_sum = l0.x; r.score_sum = l0.y; r.ret_sum = l0.z; r.len_sum = l0.w;
+        r.n_sum = l1.x; r.oob_sum = l1.y;
+    }
+    return 0;
+}
+
+int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int count) {
+    if (!v || !rows || first < 0 || count < 0 || first + count > v->n) { set_err("set_state: bad range"); return -1; }
+    if (!set_device(v)) return -1;
+    std::vector<float4> tmp((size_t)kNumPlanes * count);
+    auto f = [](uint32_t x) { float y; memcpy(&y, &x, 4); return y; };
+    for (int i = 0; i < count; i++) {
+        const DroneStateRow& r = rows[i];
+        tmp[(size_t)kP0 * count + i] = make_float4(r.pos[0], r.pos[1], r.pos[2], r.vel[0]);
+        tmp[(size_t)kP1 * count + i] = make_float4(r.vel[1], r.vel[2], r.quat[0], r.quat[1]);
+        tmp[(size_t)kP2 * count + i] = make_float4(r.quat[2], r.quat[3], r.omega[0], r.omega[1]);
+        tmp[(size_t)kP3 * count + i] = make_float4(r.omega[2], r.rpm[0], r.rpm[1], r.rpm[2]);
+        tmp[(size_t)kP4 * count + i] = make_float4(r.rpm[3], r.ep_return, f(r.tick), f(r.score_count));
+        tmp[(size_t)kPT * count + i] = make_float4(r.target[0], r.target[1], r.target[2], f(r.episode));
+        tmp[(size_t)kPW * count + i] = make_float4(r.wind[0], r.wind[1], r.wind[2], 0.0f);
+        tmp[(size_t)kL0 * count + i] = make_float4(r.perf_sum, r.score_sum, r.ret_sum, r.len_sum);
+        tmp[(size_t)kL1 * count + i] = make_float4(r.n_sum, r.oob_sum, 0.0f, 0.0f);
+    }
+    for (int p = 0; p < kNumPlanes; p++)
+        HIP_TRY(hipMemcpyAsync(v->dv.planes + (size_t)p * v->n_pad + first, tmp.data() + (size_t)p * count, sizeof(float4) * count, hipMemcpyHostToDevice, v->stream), return -1);
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    return 0;
+}
+
+int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap) {
+    if (!v || !v->dv.done_ids) { set_err("done list not enabled (compact_done=0)"); return -1; }
+    if (v->gstep == 0) return 0;
+    if (!set_device(v)) return -1;
+    uint32_t cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, v->dv.done_count + ((v->gstep - 1u) & 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, v->stream), return -1);
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    const int take = (int)cnt < cap ? (int)cnt : cap;
+    if (ids && take > 0) {
+        HIP_TRY(hipMemcpyAsync(ids, v->dv.done_ids, sizeof(uint32_t) * take, hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    }
+    return (int)cnt;
+}
+
+int drone_vec_timer_start(DroneVec* v) {
+    if (!v) return -1;
+    HIP_TRY(hipEventRecord(v->ev0, v->stream), return -1);
+    return 0;
+}
+
+int drone_vec_timer_stop(DroneVec* v, float* elapsed_ms) {
+    if (!v || !elapsed_ms) return -1;
+    HIP_TRY(hipEventRecord(v->ev1, v->stream), return -1);
+    HIP_TRY(hipEventSynchronize(v->ev1), return -1);
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, v->ev0, v->ev1), return -1);
+    return 0;
+}
+
+}  // extern "C"

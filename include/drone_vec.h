@@ -1,0 +1,143 @@
+/*
+ * drone_vec.h — C-ABI of the MI355X-native vectorised drone environment.
+ *
+ * This is the drop-in boundary: the entry points a PufferLib
+ * ocean-env binding would bind for the drone env's vec path — init / reset /
+ * step / log / close over caller-owned observation / action / reward /
+ * terminal / truncation buffers (BASELINE.json north_star: "PufferLib C env
+ * API (init/reset/step, obs/action/reward/done buffers)").
+ *
+ * Reference interface each entry point replaces: NONE CAN BE CITED. The
+ * reference snapshot has no binding source — the `pufferlib` submodule is an
+ * empty directory (/root/reference/.gitmodules:1-3) and only an older Cython
+ * shim is hinted at (/root/reference/.gitignore:14, `simulator/cy_env.c`).
+ * The shape below follows the north-star sentence; see INTEGRATION.md for the
+ * binding stub a maintainer would add on the PufferLib side.
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types in any signature
+ * (a HIP stream crosses as `void*`). Behaviour is defined by SPEC.md.
+ * The library is HIP-only: every entry point fails loudly (NULL / non-zero,
+ * message via drone_last_error()) when no gfx950 device is usable. There is
+ * no CPU fallback.
+ */
+#ifndef DRONE_VEC_H
+#define DRONE_VEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRONE_OBS_DIM 20
+#define DRONE_ACT_DIM 4
+
+#define DRONE_TASK_HOVER 0
+#define DRONE_TASK_WAYPOINT 1 /* waypoint tracking with OU wind gusts */
+
+#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory: step = H2D, kernel, D2H, sync */
+#define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
+
+/* Env kwargs. Fill with drone_config_default() first, then override. */
+typedef struct DroneConfig {
+    uint32_t struct_size; /* = sizeof(DroneConfig); checked at init */
+    int32_t task;         /* DRONE_TASK_* */
+    int32_t buffer_kind;  /* DRONE_BUFFERS_* */
+    int32_t device;       /* HIP device ordinal */
+    uint32_t env_offset;  /* global id of local env 0 (sharding; SPEC.md §2) */
+    int32_t horizon;
+    int32_t substeps;
+    int32_t compact_done; /* 1: also build the compacted done-id list each step */
+    float dt;
+    float mass, arm, ixx, iyy, izz;
+    float k_thrust, k_torque, k_drag, k_ang_damp, gravity;
+    float max_rpm, motor_tau, max_vel, max_omega;
+    float bound, spawn_extent, target_extent, tilt_init;
+    float hover_radius, waypoint_radius;
+    float wind_theta, wind_sigma, wind_max;
+    float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
+} DroneConfig;
+
+/* Aggregated episode statistics since the previous drone_vec_log (SPEC.md §8). */
+typedef struct DroneLog {
+    float perf;
+    float score;
+    float episode_return;
+    float episode_length;
+    float oob; /* fraction of episodes that ended by leaving the box */
+    float n;   /* episodes aggregated */
+} DroneLog;
+
+/* One env's full state as an AoS row — test / checkpoint interface only;
+ * the device keeps state as float4 planes. */
+typedef struct DroneStateRow {
+    float pos[3], vel[3], quat[4], omega[3], rpm[4];
+    float target[3], wind[3];
+    float ep_return;
+    uint32_t tick, episode, score_count;
+    float perf_sum, score_sum, ret_sum, len_sum, n_sum, oob_sum;
+} DroneStateRow;
+
+typedef struct DroneVec DroneVec;
+
+void drone_config_default(DroneConfig* cfg, int task);
+
+/* observations [N][20] f32, actions [N][4] f32, rewards [N] f32,
+ * terminals [N] u8, truncations [N] u8 — owned by the caller, never freed
+ * here. Returns NULL on failure (see drone_last_error). Does not reset. */
+DroneVec* drone_vec_init(float* observations, float* actions, float* rewards,
+                         unsigned char* terminals, unsigned char* truncations,
+                         int num_envs, uint64_t seed, const DroneConfig* cfg);
+
+/* Start every env's first episode from `seed`; writes observations. */
+void drone_vec_reset(DroneVec* v, uint64_t seed);
+
+/* Read `actions`, advance every env one step, overwrite observations /
+ * rewards / terminals / truncations; finished envs auto-reset (SPEC.md §5). */
+void drone_vec_step(DroneVec* v);
+
+/* Fused rollout: `horizon` steps under the device-side random policy with
+ * state held in registers; outputs written once at the horizon (SPEC.md §9).
+ * `actions` is neither read nor written. */
+void drone_vec_rollout(DroneVec* v, int horizon);
+
+void drone_vec_log(DroneVec* v, DroneLog* out);
+void drone_vec_close(DroneVec* v);
+
+/* ---- plumbing around the path ---- */
+
+/* Launch on this hipStream_t (passed as void*) from now on. Default: a
+ * stream the handle creates. Device-buffer mode is asynchronous on it. */
+int drone_vec_set_stream(DroneVec* v, void* hip_stream);
+int drone_vec_sync(DroneVec* v);
+
+/* Rebind the action buffer (same kind as at init) — lets a caller rotate
+ * through pre-filled action buffers without copies. */
+int drone_vec_bind_actions(DroneVec* v, float* actions);
+
+/* Write the SPEC.md §2 random-policy actions for step `gstep` into `actions`
+ * (same kind as the handle's buffers). */
+int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep);
+
+uint32_t drone_vec_gstep(const DroneVec* v);
+int drone_vec_num_envs(const DroneVec* v);
+
+/* Copy envs [first, first+count) to / from AoS rows (host memory). */
+int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count);
+int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int count);
+
+/* compact_done=1 only: ids (local) of the envs that finished in the last
+ * step, unordered; returns their count (or -1). Copies at most `cap` ids. */
+int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap);
+
+/* HIP-event timer on the handle's stream: start, ..launches.., stop → ms. */
+int drone_vec_timer_start(DroneVec* v);
+int drone_vec_timer_stop(DroneVec* v, float* elapsed_ms);
+
+/* Last error message of the calling thread ("" if none). */
+const char* drone_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRONE_VEC_H */

@@ -1,0 +1,363 @@
+/*
+ * drone_oracle.h — scalar CPU restatement of the drone env. TEST INFRASTRUCTURE.
+ *
+ * PARITY UNPINNED: the reference snapshot contains no simulator source (the
+ * `pufferlib` submodule is an empty directory, /root/reference/.gitmodules:1-3;
+ * SURVEY.md §8c), no tests and no golden vectors. This file therefore follows
+ * the stage list of BASELINE.json `north_star` (SURVEY.md §8a rows a1–a7) as
+ * fixed by this repo's SPEC.md, not a reference file:line. It is the oracle of
+ * record for this repo only.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * use anything in oracle/. The product (drone_amd/, include/) never does.
+ *
+ * Shape: one `Drone` struct per env with PufferLib-ocean-style entry points
+ * init / c_reset / c_step over caller-owned obs / action / reward / terminal
+ * buffers, one env at a time, array-of-structs, plain float — deliberately
+ * the opposite of the device layout so that the two implementations share no
+ * code and agreement between them means something.
+ *
+ * Build with -ffp-contract=off: the only fused operations are the fmaf()
+ * calls written out below (SPEC.md preamble).
+ */
+#ifndef DRONE_ORACLE_H
+#define DRONE_ORACLE_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/drone_vec.h"
+
+#define STREAM_RESET 0u
+#define STREAM_ACTION 1u
+#define STREAM_WIND 2u
+#define STREAM_WAYPOINT 3u
+
+/* SPEC.md §1: derived parameters, computed once, in float, in this order. */
+typedef struct Params {
+    float h, h_half, h_sixth;
+    float inv_mass, inv_ixx, inv_iyy, inv_izz;
+    float gx, gy, gz;
+    float arm_xy, drag_m, inv_tau;
+    float half_max_rpm, hover_rpm;
+    float inv_max_vel, inv_max_omega, inv_max_rpm;
+    float inv_bound, half_inv_bound;
+    float wind_decay, wind_gain;
+} Params;
+
+static inline void params_derive(const DroneConfig* c, Params* p) {
+    p->h = c->dt / (float)c->substeps;
+    p->h_half = 0.5f * p->h;
+    p->h_sixth = p->h / 6.0f;
+    p->inv_mass = 1.0f / c->mass;
+    p->inv_ixx = 1.0f / c->ixx;
+    p->inv_iyy = 1.0f / c->iyy;
+    p->inv_izz = 1.0f / c->izz;
+    p->gx = c->izz - c->iyy;
+    p->gy = c->ixx - c->izz;
+    p->gz = c->iyy - c->ixx;
+    p->arm_xy = c->arm * 0.70710678f;
+    p->drag_m = c->k_drag * p->inv_mass;
+    p->inv_tau = 1.0f / c->motor_tau;
+    p->half_max_rpm = 0.5f * c->max_rpm;
+    p->hover_rpm = sqrtf((c->mass * c->gravity) / (4.0f * c->k_thrust));
+    p->inv_max_vel = 1.0f / c->max_vel;
+    p->inv_max_omega = 1.0f / c->max_omega;
+    p->inv_max_rpm = 1.0f / c->max_rpm;
+    p->inv_bound = 1.0f / c->bound;
+    p->half_inv_bound = 0.5f * p->inv_bound;
+    p->wind_decay = 1.0f - c->wind_theta * c->dt;
+    p->wind_gain = (c->wind_sigma * sqrtf(c->dt)) * 0.0067658754f;
+}
+
+/* SPEC.md §2 */
+static inline uint32_t hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+static inline uint32_t stream_key(uint64_t seed, uint32_t stream) {
+    return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) ^ (0x9E3779B9u * (stream + 1u))));
+}
+static inline uint32_t rng_base(uint32_t key, uint32_t env, uint32_t ctr) {
+    return hash32(hash32(key ^ env) + ctr * 0x9E3779B9u);
+}
+static inline uint32_t rng_draw(uint32_t base, uint32_t d) { return hash32(base + d * 0x85EBCA6Bu); }
+static inline float u01(uint32_t u) { return (float)(u >> 8) * 5.9604645e-8f; }
+static inline float sym(uint32_t u) { return fmaf(2.0f, u01(u), -1.0f); }
+static inline float s16(uint32_t h) { return (float)((int)h - 32768) * 3.0517578125e-5f; }
+static inline float clampc(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static inline void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float a[4]) {
+    uint32_t b = rng_base(key_action, env, gstep);
+    uint32_t h0 = rng_draw(b, 0), h1 = rng_draw(b, 1);
+    a[0] = s16(h0 & 0xFFFFu);
+    a[1] = s16(h0 >> 16);
+    a[2] = s16(h1 & 0xFFFFu);
+    a[3] = s16(h1 >> 16);
+}
+
+typedef struct Log {
+    float perf, score, episode_return, episode_length, n, oob;
+} Log;
+
+/* SPEC.md §3: the 17 integrated components. */
+typedef struct State {
+    float pos[3], vel[3], quat[4], omega[3], rpm[4];
+} State;
+
+typedef struct Drone {
+    Log log; /* per-env accumulators (sums), drained by vec_log */
+    float* observations;
+    float* actions;
+    float* rewards;
+    unsigned char* terminals;
+    unsigned char* truncations;
+    State s;
+    float target[3], wind[3];
+    float ep_return;
+    uint32_t tick, episode, score_count;
+    uint32_t env_id; /* global id */
+    /* shared, read-only */
+    const DroneConfig* cfg;
+    const Params* par;
+    const uint32_t* keys;  /* [4] stream keys */
+    const uint32_t* gstep; /* vec-level step counter */
+} Drone;
+
+/* SPEC.md §4: deriv */
+static inline void deriv(const Drone* env, const State* S, const float cmd[4], State* D) {
+    const DroneConfig* c = env->cfg;
+    const Params* p = env->par;
+    const float w = S->quat[0], x = S->quat[1], y = S->quat[2], z = S->quat[3];
+    const float ox = S->omega[0], oy = S->omega[1], oz = S->omega[2];
+    float q[4], f[4];
+    for (int i = 0; i < 4; i++) {
+        q[i] = S->rpm[i] * S->rpm[i];
+        f[i] = c->k_thrust * q[i];
+    }
+    const float T = (f[0] + f[1]) + (f[2] + f[3]);
+    const float tx = p->arm_xy * ((f[0] + f[1]) - (f[2] + f[3]));
+    const float ty = p->arm_xy * ((f[1] + f[2]) - (f[0] + f[3]));
+    const float tz = c->k_torque * ((q[0] + q[2]) - (q[1] + q[3]));
+    const float zx = 2.0f * fmaf(x, z, w * y);
+    const float zy = 2.0f * fmaf(y, z, -(w * x));
+    const float zz = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
+    const float aT = T * p->inv_mass;
+    D->vel[0] = fmaf(aT, zx, -(p->drag_m * (S->vel[0] - env->wind[0])));
+    D->vel[1] = fmaf(aT, zy, -(p->drag_m * (S->vel[1] - env->wind[1])));
+    D->vel[2] = fmaf(aT, zz, -c->gravity) - p->drag_m * (S->vel[2] - env->wind[2]);
+    D->omega[0] = p->inv_ixx * ((tx - p->gx * (oy * oz)) - c->k_ang_damp * ox);
+    D->omega[1] = p->inv_iyy * ((ty - p->gy * (oz * ox)) - c->k_ang_damp * oy);
+    D->omega[2] = p->inv_izz * ((tz - p->gz * (ox * oy)) - c->k_ang_damp * oz);
+    D->quat[0] = -0.5f * fmaf(x, ox, fmaf(y, oy, z * oz));
+    D->quat[1] = 0.5f * fmaf(w, ox, fmaf(y, oz, -(z * oy)));
+    D->quat[2] = 0.5f * fmaf(w, oy, fmaf(z, ox, -(x * oz)));
+    D->quat[3] = 0.5f * fmaf(w, oz, fmaf(x, oy, -(y * ox)));
+    for (int i = 0; i < 4; i++) D->rpm[i] = (cmd[i] - S->rpm[i]) * p->inv_tau;
+    for (int i = 0; i < 3; i++) D->pos[i] = S->vel[i];
+}
+
+#define NCOMP 17 /* State is 17 contiguous floats */
+
+static inline void rk4_substep(Drone* env, const float cmd[4]) {
+    const Params* p = env->par;
+    State k, A, acc;
+    float* S = (float*)&env->s;
+    float* kk = (float*)&k;
+    float* AA = (float*)&A;
+    float* ac = (float*)&acc;
+    deriv(env, &env->s, cmd, &k);
+    for (int c = 0; c < NCOMP; c++) {
+        ac[c] = kk[c];
+        AA[c] = fmaf(p->h_half, kk[c], S[c]);
+    }
+    deriv(env, &A, cmd, &k);
+    for (int c = 0; c < NCOMP; c++) {
+        ac[c] = fmaf(2.0f, kk[c], ac[c]);
+        AA[c] = fmaf(p->h_half, kk[c], S[c]);
+    }
+    deriv(env, &A, cmd, &k);
+    for (int c = 0; c < NCOMP; c++) {
+        ac[c] = fmaf(2.0f, kk[c], ac[c]);
+        AA[c] = fmaf(p->h, kk[c], S[c]);
+    }
+    deriv(env, &A, cmd, &k);
+    for (int c = 0; c < NCOMP; c++) {
+        ac[c] = ac[c] + kk[c];
+        S[c] = fmaf(p->h_sixth, ac[c], S[c]);
+    }
+}
+
+static inline float target_dist(const Drone* env) {
+    const float dx = env->target[0] - env->s.pos[0];
+    const float dy = env->target[1] - env->s.pos[1];
+    const float dz = env->target[2] - env->s.pos[2];
+    return sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+}
+
+/* SPEC.md §7 */
+static inline void compute_observations(Drone* env) {
+    const DroneConfig* c = env->cfg;
+    const Params* p = env->par;
+    const State* s = &env->s;
+    const float w = s->quat[0], x = s->quat[1], y = s->quat[2], z = s->quat[3];
+    const float r00 = fmaf(-2.0f, fmaf(y, y, z * z), 1.0f);
+    const float r01 = 2.0f * fmaf(x, y, -(w * z));
+    const float r02 = 2.0f * fmaf(x, z, w * y);
+    const float r10 = 2.0f * fmaf(x, y, w * z);
+    const float r11 = fmaf(-2.0f, fmaf(x, x, z * z), 1.0f);
+    const float r12 = 2.0f * fmaf(y, z, -(w * x));
+    const float r20 = 2.0f * fmaf(x, z, -(w * y));
+    const float r21 = 2.0f * fmaf(y, z, w * x);
+    const float r22 = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
+    float* o = env->observations;
+    const float* v = s->vel;
+    o[0] = fmaf(r00, v[0], fmaf(r10, v[1], r20 * v[2])) * p->inv_max_vel;
+    o[1] = fmaf(r01, v[0], fmaf(r11, v[1], r21 * v[2])) * p->inv_max_vel;
+    o[2] = fmaf(r02, v[0], fmaf(r12, v[1], r22 * v[2])) * p->inv_max_vel;
+    for (int i = 0; i < 3; i++) o[3 + i] = s->omega[i] * p->inv_max_omega;
+    for (int i = 0; i < 4; i++) o[6 + i] = s->quat[i];
+    for (int i = 0; i < 4; i++) o[10 + i] = s->rpm[i] * p->inv_max_rpm;
+    const float e0 = env->target[0] - s->pos[0];
+    const float e1 = env->target[1] - s->pos[1];
+    const float e2 = env->target[2] - s->pos[2];
+    o[14] = fmaf(r00, e0, fmaf(r10, e1, r20 * e2)) * p->half_inv_bound;
+    o[15] = fmaf(r01, e0, fmaf(r11, e1, r21 * e2)) * p->half_inv_bound;
+    o[16] = fmaf(r02, e0, fmaf(r12, e1, r22 * e2)) * p->half_inv_bound;
+    for (int i = 0; i < 3; i++) o[17 + i] = s->pos[i] * p->inv_bound;
+    (void)c;
+}
+
+/* SPEC.md §6 (state only; the episode counter is the caller's business) */
+static inline void reset_state(Drone* env) {
+    const DroneConfig* c = env->cfg;
+    const uint32_t b = rng_base(env->keys[STREAM_RESET], env->env_id, env->episode);
+    float t[3];
+    for (uint32_t i = 0; i < 3; i++) {
+        env->s.pos[i] = c->spawn_extent * sym(rng_draw(b, i));
+        env->target[i] = c->target_extent * sym(rng_draw(b, 3 + i));
+        t[i] = c->tilt_init * sym(rng_draw(b, 6 + i));
+    }
+    const float n2 = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], 1.0f)));
+    const float inv = 1.0f / sqrtf(n2);
+    env->s.quat[0] = inv;
+    env->s.quat[1] = t[0] * inv;
+    env->s.quat[2] = t[1] * inv;
+    env->s.quat[3] = t[2] * inv;
+    for (int i = 0; i < 3; i++) {
+        env->s.vel[i] = 0.0f;
+        env->s.omega[i] = 0.0f;
+        env->wind[i] = 0.0f;
+    }
+    for (int i = 0; i < 4; i++) env->s.rpm[i] = env->par->hover_rpm;
+    env->tick = 0;
+    env->score_count = 0;
+    env->ep_return = 0.0f;
+}
+
+static inline void init(Drone* env) {
+    memset(&env->log, 0, sizeof(Log));
+    memset(&env->s, 0, sizeof(State));
+    env->episode = 0;
+}
+
+/* First episode of this env (vec_reset): SPEC.md §6 last paragraph. */
+static inline void c_reset(Drone* env) {
+    memset(&env->log, 0, sizeof(Log));
+    env->episode = 0;
+    reset_state(env);
+    compute_observations(env);
+    env->rewards[0] = 0.0f;
+    env->terminals[0] = 0;
+    env->truncations[0] = 0;
+}
+
+/* SPEC.md §5 */
+static inline void c_step(Drone* env) {
+    const DroneConfig* c = env->cfg;
+    const Params* p = env->par;
+    State* s = &env->s;
+    float a[4], cmd[4];
+    for (int i = 0; i < 4; i++) {
+        a[i] = clampc(env->actions[i], -1.0f, 1.0f);
+        cmd[i] = p->half_max_rpm * (a[i] + 1.0f);
+    }
+    float prev_dist = 0.0f;
+    if (c->task == DRONE_TASK_WAYPOINT) {
+        const uint32_t b = rng_base(env->keys[STREAM_WIND], env->env_id, *env->gstep);
+        for (uint32_t i = 0; i < 3; i++) {
+            const uint32_t u = rng_draw(b, i);
+            const uint32_t sum = (u & 255u) + ((u >> 8) & 255u) + ((u >> 16) & 255u) + (u >> 24);
+            const float xi = (float)((int)sum - 510);
+            env->wind[i] = clampc(fmaf(p->wind_decay, env->wind[i], p->wind_gain * xi), -c->wind_max, c->wind_max);
+        }
+        prev_dist = target_dist(env);
+    }
+
+    for (int k = 0; k < c->substeps; k++) rk4_substep(env, cmd);
+    {
+        float* q = s->quat;
+        const float n2 = fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3])));
+        const float inv = 1.0f / sqrtf(n2);
+        for (int i = 0; i < 4; i++) q[i] = q[i] * inv;
+        for (int i = 0; i < 3; i++) s->vel[i] = clampc(s->vel[i], -c->max_vel, c->max_vel);
+        for (int i = 0; i < 3; i++) s->omega[i] = clampc(s->omega[i], -c->max_omega, c->max_omega);
+        for (int i = 0; i < 4; i++) s->rpm[i] = clampc(s->rpm[i], 0.0f, c->max_rpm);
+    }
+    env->tick += 1;
+
+    const float dist = target_dist(env);
+    const int oob = !(fabsf(s->pos[0]) <= c->bound) || !(fabsf(s->pos[1]) <= c->bound) || !(fabsf(s->pos[2]) <= c->bound);
+    const int trunc = !oob && env->tick >= (uint32_t)c->horizon;
+
+    const float w2 = fmaf(s->omega[0], s->omega[0], fmaf(s->omega[1], s->omega[1], s->omega[2] * s->omega[2]));
+    const float a2 = fmaf(a[0], a[0], fmaf(a[1], a[1], fmaf(a[2], a[2], a[3] * a[3])));
+    const float pen = fmaf(c->c_omega, w2, c->c_action * a2);
+    float r;
+    if (c->task == DRONE_TASK_HOVER) {
+        r = 1.0f / (1.0f + dist) - pen;
+        if (dist < c->hover_radius) env->score_count += 1;
+    } else {
+        r = c->progress_scale * (prev_dist - dist) - pen;
+        if (!oob && dist < c->waypoint_radius) {
+            r += c->waypoint_bonus;
+            env->score_count += 1;
+            const uint32_t b = rng_base(env->keys[STREAM_WAYPOINT], env->env_id, env->episode);
+            for (uint32_t i = 0; i < 3; i++)
+                env->target[i] = c->target_extent * sym(rng_draw(b, 3u * env->score_count + i));
+        }
+    }
+    if (oob) r -= c->crash_penalty;
+
+    env->ep_return += r;
+    env->rewards[0] = r;
+    env->terminals[0] = (unsigned char)oob;
+    env->truncations[0] = (unsigned char)trunc;
+
+    if (oob || trunc) {
+        float score, perf;
+        if (c->task == DRONE_TASK_HOVER) {
+            score = (float)env->score_count / (float)env->tick;
+            perf = score;
+        } else {
+            score = (float)env->score_count;
+            perf = env->score_count >= 8u ? 1.0f : (float)env->score_count * 0.125f;
+        }
+        env->log.perf += perf;
+        env->log.score += score;
+        env->log.episode_return += env->ep_return;
+        env->log.episode_length += (float)env->tick;
+        env->log.n += 1.0f;
+        env->log.oob += oob ? 1.0f : 0.0f;
+        env->episode += 1;
+        reset_state(env);
+    }
+    compute_observations(env);
+}
+
+#endif /* DRONE_ORACLE_H */
