@@ -1,0 +1,190 @@
+"""ctypes binding of ``libdrone_hip.so`` — the C-ABI of ``include/drone_vec.h``.
+
+This is the host-side mirror of what PufferLib's env binding does for the
+drone env's vec path (vec_init / vec_reset / vec_step / vec_log / vec_close
+over shared buffers; SURVEY.md §3, §8b — the reference binding itself is not
+in the snapshot, ``/root/reference/.gitmodules:1-3``).
+
+The product path is HIP only: loading fails loudly if the shared object has
+not been built, and ``DroneVec`` raises if ``drone_vec_init`` returns NULL
+(no GPU, wrong arch). There is no CPU fallback anywhere in ``drone_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libdrone_hip.so")
+_lib = None
+_fns = None
+
+
+def load():
+    """Load libdrone_hip.so (once). torch is imported first so that the
+    library binds to the same HIP runtime instance torch uses."""
+    global _lib, _fns
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C drone_amd/csrc)")
+        try:
+            import torch  # noqa: F401  (same libamdhip64 for tensors, streams and RCCL)
+        except ImportError:
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        _fns = abi.bind(_lib)
+    return _lib
+
+
+def last_error():
+    load()
+    return _fns["drone_last_error"]().decode()
+
+
+def default_config(task=abi.TASK_HOVER, **overrides):
+    load()
+    cfg = abi.DroneConfig()
+    _fns["drone_config_default"](C.byref(cfg), task)
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(f"DroneConfig has no field {k!r}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    return x.data_ptr() if _is_torch(x) else x.ctypes.data
+
+
+class DroneVec:
+    """One shard of envs on one GPU.
+
+    ``device=None``: numpy host buffers (each step copies actions in and
+    observations / rewards / flags out). ``device="cuda:0"`` (or an index):
+    torch tensors in HBM, zero-copy, launches asynchronous on torch's current
+    stream for that device.
+    """
+
+    def __init__(self, num_envs, seed=0, task=abi.TASK_HOVER, device=None, cfg=None, **overrides):
+        load()
+        self.num_envs = int(num_envs)
+        n = self.num_envs
+        self.cfg = cfg if cfg is not None else default_config(task, **overrides)
+        self._h = None
+        if device is None:
+            self.torch_device = None
+            self.cfg.buffer_kind = abi.BUFFERS_HOST
+            self.observations = np.zeros((n, abi.OBS_DIM), dtype=np.float32)
+            self.actions = np.zeros((n, abi.ACT_DIM), dtype=np.float32)
+            self.rewards = np.zeros(n, dtype=np.float32)
+            self.terminals = np.zeros(n, dtype=np.uint8)
+            self.truncations = np.zeros(n, dtype=np.uint8)
+        else:
+            import torch
+
+            dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+            if dev.type != "cuda":
+                raise ValueError("device buffers must live on a GPU")
+            self.torch_device = dev
+            self.cfg.buffer_kind = abi.BUFFERS_DEVICE
+            self.cfg.device = dev.index if dev.index is not None else torch.cuda.current_device()
+            self.observations = torch.zeros((n, abi.OBS_DIM), dtype=torch.float32, device=dev)
+            self.actions = torch.zeros((n, abi.ACT_DIM), dtype=torch.float32, device=dev)
+            self.rewards = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.terminals = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self.truncations = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._h = _fns["drone_vec_init"](
+            _ptr(self.observations), _ptr(self.actions), _ptr(self.rewards), _ptr(self.terminals), _ptr(self.truncations),
+            n, seed, C.byref(self.cfg))
+        if not self._h:
+            raise RuntimeError("drone_vec_init failed: " + last_error())
+        if self.torch_device is not None:
+            self.use_torch_stream()
+
+    # -- stream plumbing --
+    def use_torch_stream(self):
+        import torch
+
+        s = torch.cuda.current_stream(self.torch_device)
+        self._check(_fns["drone_vec_set_stream"](self._h, C.c_void_p(s.cuda_stream)))
+
+    def sync(self):
+        self._check(_fns["drone_vec_sync"](self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("libdrone_hip: " + last_error())
+
+    # -- the path --
+    def reset(self, seed=0):
+        _fns["drone_vec_reset"](self._h, seed)
+
+    def step(self):
+        _fns["drone_vec_step"](self._h)
+
+    def rollout(self, horizon):
+        _fns["drone_vec_rollout"](self._h, int(horizon))
+
+    def log(self):
+        out = abi.DroneLog()
+        _fns["drone_vec_log"](self._h, C.byref(out))
+        return out.as_dict()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _fns["drone_vec_close"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- around the path --
+    @property
+    def gstep(self):
+        return _fns["drone_vec_gstep"](self._h)
+
+    def bind_actions(self, actions):
+        self._check(_fns["drone_vec_bind_actions"](self._h, _ptr(actions)))
+        self.actions = actions
+
+    def fill_random_actions(self, gstep=None, out=None):
+        out = self.actions if out is None else out
+        g = self.gstep if gstep is None else gstep
+        self._check(_fns["drone_vec_fill_random_actions"](self._h, _ptr(out), g))
+        return out
+
+    def get_state(self, first=0, count=None):
+        count = self.num_envs - first if count is None else count
+        rows = np.zeros(count, dtype=abi.state_row_dtype())
+        self._check(_fns["drone_vec_get_state"](self._h, rows.ctypes.data, first, count))
+        return rows
+
+    def set_state(self, rows, first=0):
+        rows = np.ascontiguousarray(rows, dtype=abi.state_row_dtype())
+        self._check(_fns["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows)))
+
+    def done_list(self):
+        ids = np.zeros(self.num_envs, dtype=np.uint32)
+        cnt = _fns["drone_vec_done_list"](self._h, ids.ctypes.data, self.num_envs)
+        if cnt < 0:
+            raise RuntimeError("libdrone_hip: " + last_error())
+        return ids[:cnt]
+
+    def timer_start(self):
+        self._check(_fns["drone_vec_timer_start"](self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._check(_fns["drone_vec_timer_stop"](self._h, C.byref(ms)))
+        return ms.value

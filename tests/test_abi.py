@@ -1,0 +1,83 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every
+symbol include/drone_vec.h declares, agrees with the header on struct sizes,
+and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from drone_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "drone_vec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(drone_[a-z_0-9]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_and_ctypes_table_agree():
+    assert header_functions() == sorted(abi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(hip):
+    lib = hip.load()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """Ask the C compiler for sizeof/offsetof of the header's structs and compare
+    with the ctypes mirror field by field."""
+    import subprocess
+
+    lines = []
+    for sname, cls in (("DroneConfig", abi.DroneConfig), ("DroneLog", abi.DroneLog), ("DroneStateRow", abi.DroneStateRow)):
+        lines.append(f'printf("{sname} %zu\\n", sizeof({sname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{sname}.{fname} %zu\\n", offsetof({sname}, {fname}));')
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "drone_vec.h"\nint main(void){' + "".join(lines) + "return 0;}"
+    c = tmp_path / "layout.c"
+    c.write_text(src)
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for sname, cls in (("DroneConfig", abi.DroneConfig), ("DroneLog", abi.DroneLog), ("DroneStateRow", abi.DroneStateRow)):
+        assert int(got[sname]) == C.sizeof(cls), sname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{sname}.{fname}"]) == getattr(cls, fname).offset, f"{sname}.{fname}"
+    assert abi.state_row_dtype().itemsize == C.sizeof(abi.DroneStateRow)
+    for fname in abi.state_row_dtype().names:
+        assert abi.state_row_dtype().fields[fname][1] == getattr(abi.DroneStateRow, fname).offset
+
+
+def test_default_config_matches_oracle(hip, oracle):
+    for task in (0, 1):
+        a = hip.default_config(task).as_dict()
+        b = oracle.default_config(task).as_dict()
+        assert a == b
+        assert a["struct_size"] == C.sizeof(abi.DroneConfig)
+
+
+def test_no_gpu_means_loud_failure(hip):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="drone_vec_init failed"):
+        hip.DroneVec(8)
+    assert hip.last_error() != ""
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference oracle/ in any form."""
+    pkg = os.path.join(ROOT, "drone_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                code = "\n".join(l for l in text.splitlines() if not l.strip().startswith(("#", "//", "*", "/*", '"""')))
+                assert not re.search(r"(import|from)\s+oracle|include\s+[\"<].*oracle|liboracle|libdrone_oracle", code), os.path.join(dirpath, f)

@@ -1,0 +1,210 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeds and action sequences. Bit-exact (tolerance 0) for
+state, observations, rewards and flags; the north-star's bound is 1e-5
+relative over 1000 steps. Parity is with THIS REPO'S oracle — upstream parity
+is unpinned."""
+import numpy as np
+import pytest
+
+from drone_amd import abi
+from helpers import assert_bits_equal, assert_outputs_equal, assert_state_equal, max_rel_state_error, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(oracle, hip, n, seed, task=0, device=None, **over):
+    ocfg = oracle.default_config(task, **over)
+    hcfg = hip.default_config(task, **over)
+    o = oracle.OracleVec(n, seed=seed, cfg=ocfg, threads=8)
+    h = hip.DroneVec(n, seed=seed, cfg=hcfg, device=device)
+    o.reset(seed)
+    h.reset(seed)
+    return o, h
+
+
+def set_actions(h, a):
+    if h.torch_device is None:
+        h.actions[:] = a
+    else:
+        import torch
+
+        h.actions.copy_(torch.from_numpy(a))
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_reset_matches(oracle, hip, task):
+    o, h = make_pair(oracle, hip, 1000, 7, task)
+    assert_state_equal(o.get_state(), h.get_state(), "reset state")
+    assert_outputs_equal(o, h, "reset")
+
+
+@pytest.mark.parametrize("task,n,horizon", [(0, 1024, 1024), (1, 1024, 1024), (0, 333, 50), (1, 777, 64)])
+def test_1000_step_random_rollout_bit_exact(oracle, hip, task, n, horizon):
+    """BASELINE.json config 1 (1024 envs, random actions) and the truncation path."""
+    o, h = make_pair(oracle, hip, n, 2024, task, horizon=horizon)
+    terms = truncs = 0
+    for t in range(1000):
+        o.fill_random_actions()
+        set_actions(h, o.actions)
+        o.step()
+        h.step()
+        assert_outputs_equal(o, h, f"step {t}")
+        terms += int(o.terminals.sum())
+        truncs += int(o.truncations.sum())
+        if t % 100 == 99:
+            assert_state_equal(o.get_state(), h.get_state(), f"state@{t}")
+    so, sh = o.get_state(), h.get_state()
+    assert_state_equal(so, sh, "final state")
+    assert max_rel_state_error(so, sh) <= 1e-5  # north-star bound; actual 0
+    if horizon < 100:
+        assert truncs > 0
+    else:
+        assert terms > 0
+    lo, lh = o.log(), h.log()
+    assert lo["n"] == lh["n"] and lo["n"] > 0
+    for k in lo:
+        assert lh[k] == pytest.approx(lo[k], rel=1e-6, abs=1e-7), k
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 4097])
+def test_ragged_sizes(oracle, hip, n):
+    o, h = make_pair(oracle, hip, n, 5, 1, horizon=20)
+    for t in range(60):
+        o.fill_random_actions()
+        set_actions(h, o.actions)
+        o.step()
+        h.step()
+        assert_outputs_equal(o, h, f"n={n} step {t}")
+    assert_state_equal(o.get_state(), h.get_state(), f"n={n}")
+
+
+def test_device_random_policy_matches_oracle(oracle, hip):
+    o, h = make_pair(oracle, hip, 1500, 99, 0, env_offset=12345)
+    for g in (0, 1, 77, 2**31 + 5):
+        a = o.fill_random_actions(gstep=g).copy()
+        b = h.fill_random_actions(gstep=g)
+        assert_bits_equal(a, b, f"random actions gstep={g}")
+    assert np.all(a >= -1.0) and np.all(a < 1.0)
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_fused_rollout_equals_stepping(oracle, hip, task):
+    """SPEC.md §9 / BASELINE.json config 5 at test size."""
+    o, h = make_pair(oracle, hip, 2000, 11, task, horizon=100)
+    for T in (1, 128, 37):
+        o.rollout(T)
+        h.rollout(T)
+        assert o.gstep == h.gstep
+        assert_outputs_equal(o, h, f"rollout T={T}")
+        assert_state_equal(o.get_state(), h.get_state(), f"rollout T={T}")
+    # and the fused kernel against the per-step kernel on the device itself
+    h2 = hip.DroneVec(2000, seed=11, cfg=hip.default_config(task, horizon=100))
+    h2.reset(11)
+    for _ in range(1 + 128 + 37):
+        h2.fill_random_actions()
+        h2.step()
+    assert_state_equal(h.get_state(), h2.get_state(), "fused vs stepped on device")
+
+
+def test_shard_invariance(oracle, hip):
+    """Envs [0,N) as one vec == two vecs with env_offset (multi-GPU sharding)."""
+    n, half = 1024, 512
+    whole = hip.DroneVec(n, seed=3, cfg=hip.default_config(1))
+    lo = hip.DroneVec(half, seed=3, cfg=hip.default_config(1, env_offset=0))
+    hi = hip.DroneVec(half, seed=3, cfg=hip.default_config(1, env_offset=half))
+    for v in (whole, lo, hi):
+        v.reset(3)
+        v.rollout(300)
+    sw = whole.get_state()
+    assert_state_equal(sw[:half], lo.get_state(), "lower shard")
+    assert_state_equal(sw[half:], hi.get_state(), "upper shard")
+    assert_bits_equal(whole.observations[half:], hi.observations, "upper shard obs")
+
+
+def test_edge_states_nan_and_bounds(oracle, hip):
+    """Injected states: on the bound, just outside, NaN position, huge velocity,
+    zero quaternion, tick at the horizon."""
+    n = 256
+    o, h = make_pair(oracle, hip, n, 21, 0)
+    rows = o.get_state()
+    b = 5.0
+    rows["pos"][0] = (b, 0, 0)                      # exactly on the bound: inside
+    rows["pos"][1] = (np.nextafter(np.float32(b), np.float32(10)), 0, 0)
+    rows["pos"][2] = (np.nan, 0, 0)
+    rows["vel"][3] = (1e30, -1e30, 1e30)
+    rows["quat"][4] = (0, 0, 0, 0)                  # 1/sqrt(0) -> inf -> NaN -> oob
+    rows["tick"][5] = 1023                          # truncates on this step
+    rows["omega"][6] = (1e6, -1e6, 1e6)
+    rows["rpm"][7] = (-5, 1e9, 0, 21702)
+    rows["pos"][8] = (0, 0, -b)
+    rows["vel"][8] = (0, 0, -20)
+    o.set_state(rows)
+    h.set_state(rows)
+    assert_state_equal(o.get_state(), h.get_state(), "after set_state")
+    acts = np.zeros((n, 4), np.float32)
+    acts[10] = (np.nan, 2.0, -3.0, np.inf)
+    acts[11] = (1.0, -1.0, 1.0, -1.0)
+    for t in range(3):
+        o.actions[:] = acts
+        set_actions(h, acts)
+        o.step()
+        h.step()
+        assert_outputs_equal(o, h, f"edge step {t}")
+        assert_state_equal(o.get_state(), h.get_state(), f"edge state {t}")
+        if t == 0:
+            assert o.terminals[1] == 1 and o.terminals[2] == 1 and o.terminals[0] == 0 and o.truncations[5] == 1
+    assert np.isfinite(to_np(h.observations)[:10]).all()
+
+
+def test_done_list_compaction(oracle, hip):
+    n = 3000
+    o, h = make_pair(oracle, hip, n, 8, 0, horizon=40, compact_done=1)
+    seen = 0
+    for t in range(120):
+        o.fill_random_actions()
+        set_actions(h, o.actions)
+        o.step()
+        h.step()
+        want = np.flatnonzero(o.terminals | o.truncations).astype(np.uint32)
+        got = np.sort(h.done_list())
+        assert_bits_equal(want, got, f"done ids step {t}")
+        seen += len(want)
+    assert seen > n
+
+
+def test_device_buffers_torch(oracle, hip):
+    """Zero-copy mode: torch tensors in HBM, launches on torch's stream."""
+    import torch
+
+    o, h = make_pair(oracle, hip, 5000, 31, 1, device="cuda:0")
+    for t in range(200):
+        o.fill_random_actions()
+        h.fill_random_actions()
+        assert_bits_equal(o.actions, h.actions, "device actions")
+        o.step()
+        h.step()
+    torch.cuda.synchronize()
+    assert_outputs_equal(o, h, "device-buffer step")
+    assert_state_equal(o.get_state(), h.get_state(), "device-buffer state")
+    # action ring via bind_actions
+    ring = [torch.zeros_like(h.actions) for _ in range(3)]
+    for k, r in enumerate(ring):
+        h.fill_random_actions(gstep=h.gstep + k, out=r)
+    for k, r in enumerate(ring):
+        o.fill_random_actions()
+        o.step()
+        h.bind_actions(r)
+        h.step()
+    torch.cuda.synchronize()
+    assert_outputs_equal(o, h, "ring step")
+
+
+def test_init_failures_are_loud(hip):
+    cfg = hip.default_config(0)
+    cfg.struct_size = 4
+    with pytest.raises(RuntimeError, match="struct_size"):
+        hip.DroneVec(16, cfg=cfg)
+    with pytest.raises(RuntimeError, match="not available"):
+        hip.DroneVec(16, cfg=hip.default_config(0, device=63))
+    with pytest.raises(RuntimeError):
+        hip.DroneVec(0)
