@@ -17,7 +17,8 @@ import numpy as np
 from . import abi
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libdrone_hip.so")
+# DRONE_HIP_LIB: alternative build of the same library (tuning experiments only)
+LIB_PATH = os.environ.get("DRONE_HIP_LIB") or os.path.join(_DIR, "libdrone_hip.so")
 _lib = None
 _fns = None
 

@@ -15,6 +15,7 @@ struct DeviceView {
     uint32_t n;          // envs on this device
     uint32_t n_pad;      // plane stride (multiple of kBlock)
     const uint32_t* kp;  // KParams in HBM (kParamWords words) — staged to LDS per workgroup
+    const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)
     float* obs;          // [n][20]
     const float* act;    // [n][4]
     float* rew;          // [n]

@@ -18,6 +18,23 @@
 #include "drone_kernels.h"
 #include "drone_lane.hpp"
 
+// ---- tuning knobs (compile-time; defaults are the measured best) ----
+#ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset
+#define DRONE_STEP_MIN_WAVES 0
+#endif
+#ifndef DRONE_OBS_VIA_LDS  // 1: transpose observation rows through LDS; 0: strided per-lane row stores
+#define DRONE_OBS_VIA_LDS 1
+#endif
+#ifndef DRONE_NT_STORES  // 1: non-temporal stores for the outputs nobody on the GPU re-reads
+#define DRONE_NT_STORES 0
+#endif
+#ifndef DRONE_PARAMS_IN_SGPR  // 1: constants from the kernarg segment (scalar loads) instead of the LDS block
+#define DRONE_PARAMS_IN_SGPR 0
+#endif
+#ifndef DRONE_PERSISTENT_BLOCKS_PER_CU  // >0: cap the grid at this many workgroups per CU and loop over chunks
+#define DRONE_PERSISTENT_BLOCKS_PER_CU 0
+#endif
+
 namespace drone {
 
 namespace {
@@ -28,6 +45,15 @@ constexpr int kObsVec = DRONE_OBS_DIM / 4;  // float4 per obs row = 5
 
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+template <typename T>
+__device__ __forceinline__ void out_store(T* p, const T& v) {
+#if DRONE_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 // ---- constants: HBM -> LDS, once per workgroup ----
 __device__ __forceinline__ void stage_params(KParams& sp, const uint32_t* __restrict__ kp) {
@@ -84,7 +110,7 @@ __device__ __forceinline__ void store_obs_wave(float* __restrict__ obs, float4* 
 #pragma unroll
     for (int k = 0; k < kObsVec; k++) {
         const uint32_t j = k * kWave + lane;
-        if (j < rows * kObsVec) dst[j] = tile[j];
+        if (j < rows * kObsVec) out_store(&dst[j], tile[j]);
     }
 }
 
@@ -106,25 +132,30 @@ struct StepArgs {
     DeviceView v;
     uint32_t gstep;
     uint32_t flags_aligned;  // bit0: term 4-B aligned, bit1: trunc 4-B aligned
+#if DRONE_PARAMS_IN_SGPR
+    KParams kp_val;          // constants by value: read with scalar loads from the kernarg segment
+#endif
 };
 
-// =====================================================================
-// per-step kernel (SPEC.md §5): configs 1–4
-// =====================================================================
-template <int TASK, bool COMPACT>
-__global__ __launch_bounds__(kBlock) void drone_step_kernel(StepArgs a) {
-    __shared__ KParams sp;
-    __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
-    stage_params(sp, a.v.kp);
+// Observation rows without the LDS transpose: each lane stores its own 80-B row.
+[[maybe_unused]] __device__ __forceinline__ void store_obs_direct(float* __restrict__ obs, const float (&o)[DRONE_OBS_DIM], uint32_t i, bool valid) {
+    if (!valid) return;
+    float4* dst = reinterpret_cast<float4*>(obs + (size_t)i * DRONE_OBS_DIM);
+#pragma unroll
+    for (int k = 0; k < kObsVec; k++) out_store(&dst[k], make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]));
+}
 
+// One 256-drone chunk of the per-step path.
+template <int TASK, bool COMPACT>
+__device__ __forceinline__ void step_chunk(const StepArgs& a, const KParams& sp, float4 (*obs_tile)[kWave * kObsVec], uint32_t chunk) {
     const uint32_t n = a.v.n, np = a.v.n_pad;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = chunk * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t wave_base = i - lane;
     const bool valid = i < n;
     // planes are padded to n_pad, so loads of the padding lanes are in bounds;
-    // they compute on zeros and store nothing.
+    // they compute on the reset state and store nothing.
     Lane L;
     load_lane<TASK>(a.v.planes, np, i, L);
     float act[4];
@@ -139,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void drone_step_kernel(StepArgs a) {
 
     if (valid) {
         store_lane<TASK>(a.v.planes, np, i, L, out.target_changed);
-        a.v.rew[i] = out.reward;
+        out_store(&a.v.rew[i], out.reward);
         if (done) {  // rare: fold the finished episode into this env's log sums
             float4 l0 = a.v.planes[kL0 * np + i];
             float4 l1 = a.v.planes[kL1 * np + i];
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void drone_step_kernel(StepArgs a) {
     if (COMPACT) {
         const uint64_t m_done = m_term | m_trunc;
         uint32_t* cnt = a.v.done_count + (a.gstep & 1u);
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[(a.gstep + 1u) & 1u] = 0u;  // arm the next step's counter
+        if (chunk == 0 && threadIdx.x == 0) a.v.done_count[(a.gstep + 1u) & 1u] = 0u;  // arm the next step's counter
         if (m_done != 0) {  // wave-uniform
             const uint32_t total = (uint32_t)__popcll(m_done);
             uint32_t base = 0;
@@ -173,7 +204,46 @@ __global__ __launch_bounds__(kBlock) void drone_step_kernel(StepArgs a) {
 
     float o[DRONE_OBS_DIM];
     lane_obs(sp, L, o);
+#if DRONE_OBS_VIA_LDS
     store_obs_wave(a.v.obs, obs_tile[wave], o, wave_base < n ? wave_base : 0u, wave_base < n ? n : 0u, lane);
+#else
+    store_obs_direct(a.v.obs, o, i, valid);
+#endif
+}
+
+// =====================================================================
+// per-step kernel (SPEC.md §5): configs 1–4
+// =====================================================================
+#if DRONE_STEP_MIN_WAVES > 0
+#define DRONE_STEP_BOUNDS __launch_bounds__(kBlock, DRONE_STEP_MIN_WAVES)
+#else
+#define DRONE_STEP_BOUNDS __launch_bounds__(kBlock)
+#endif
+
+template <int TASK, bool COMPACT>
+__global__ DRONE_STEP_BOUNDS void drone_step_kernel(StepArgs a) {
+#if DRONE_OBS_VIA_LDS
+    __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
+#else
+    float4 (*obs_tile)[kWave * kObsVec] = nullptr;
+#endif
+#if DRONE_PARAMS_IN_SGPR
+    const KParams& sp = a.kp_val;
+#else
+    __shared__ KParams sp;
+    stage_params(sp, a.v.kp);
+#endif
+#if DRONE_PERSISTENT_BLOCKS_PER_CU > 0
+    const uint32_t chunks = (a.v.n + kBlock - 1) / kBlock;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        step_chunk<TASK, COMPACT>(a, sp, obs_tile, chunk);
+#if DRONE_OBS_VIA_LDS
+        __syncthreads();  // the tile is reused by the next chunk
+#endif
+    }
+#else
+    step_chunk<TASK, COMPACT>(a, sp, obs_tile, blockIdx.x);
+#endif
 }
 
 // =====================================================================
@@ -312,6 +382,9 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     StepArgs a;
     a.v = v;
     a.gstep = gstep;
+#if DRONE_PARAMS_IN_SGPR
+    a.kp_val = *v.kp_host;
+#endif
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 3u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 3u) == 0 ? 2u : 0u);
     return a;
 }
@@ -328,7 +401,11 @@ hipError_t launch_reset(const DeviceView& v, hipStream_t s) {
 
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s) {
     const StepArgs a = make_args(v, gstep);
-    const dim3 g(grid_for(v.n)), b(kBlock);
+    unsigned blocks = grid_for(v.n);
+#if DRONE_PERSISTENT_BLOCKS_PER_CU > 0
+    if (blocks > 256u * DRONE_PERSISTENT_BLOCKS_PER_CU) blocks = 256u * DRONE_PERSISTENT_BLOCKS_PER_CU;
+#endif
+    const dim3 g(blocks), b(kBlock);
     const bool compact = v.done_ids != nullptr;
     if (task == DRONE_TASK_HOVER) {
         if (compact) drone_step_kernel<DRONE_TASK_HOVER, true><<<g, b, 0, s>>>(a);

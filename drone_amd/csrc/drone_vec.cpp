@@ -238,6 +238,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->dv.n = (uint32_t)num_envs;
     v->dv.n_pad = v->n_pad;
     v->dv.kp = v->d_kp;
+    v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
 #undef INIT_TRY
     return v;

@@ -1,0 +1,69 @@
+"""Sharding of envs over the GPUs of one node.
+
+Envs are independent, so the path shards with no data-path collective: rank r
+owns a contiguous range of global env ids and passes its start as
+``env_offset`` (the counter RNG is keyed on the GLOBAL id, SPEC.md §2, so the
+trajectory of env e does not depend on the shard it lands in). The only
+exchange is at the host boundary: an all-gather of observations / rewards /
+flags for a consumer that wants the whole batch on every rank (RCCL over xGMI
+when the tensors are in HBM; the same code runs on gloo with CPU tensors).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs, rank, world):
+    """Contiguous split; the first ``total % world`` ranks get one extra env."""
+    base, extra = divmod(int(total_envs), int(world))
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def shard_counts(total_envs, world):
+    return [shard_range(total_envs, r, world)[1] for r in range(world)]
+
+
+class BoundaryGather:
+    """Pre-allocated all-gather of the per-step outputs of every shard.
+
+    Equal shards use ``all_gather_into_tensor`` straight into the global
+    buffers (one collective per buffer, no staging). Ragged shards pad to the
+    largest shard and trim on arrival.
+    """
+
+    def __init__(self, total_envs, obs_dim, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.total = int(total_envs)
+        self.counts = shard_counts(self.total, self.world)
+        self.equal = len(set(self.counts)) == 1
+        self.max_count = max(self.counts)
+        rows = self.total if self.equal else self.max_count * self.world
+        self.obs = torch.empty((rows, obs_dim), dtype=torch.float32, device=device)
+        self.rew = torch.empty(rows, dtype=torch.float32, device=device)
+        self.term = torch.empty(rows, dtype=torch.uint8, device=device)
+        self.trunc = torch.empty(rows, dtype=torch.uint8, device=device)
+        if not self.equal:
+            self._pad = {
+                "obs": torch.zeros((self.max_count, obs_dim), dtype=torch.float32, device=device),
+                "rew": torch.zeros(self.max_count, dtype=torch.float32, device=device),
+                "term": torch.zeros(self.max_count, dtype=torch.uint8, device=device),
+                "trunc": torch.zeros(self.max_count, dtype=torch.uint8, device=device),
+            }
+
+    def __call__(self, obs, rew, term, trunc):
+        """Gather this rank's outputs; returns global (obs, rew, term, trunc) in env-id order."""
+        srcs = {"obs": obs, "rew": rew, "term": term, "trunc": trunc}
+        dsts = {"obs": self.obs, "rew": self.rew, "term": self.term, "trunc": self.trunc}
+        if self.equal:
+            for k in srcs:
+                dist.all_gather_into_tensor(dsts[k], srcs[k].contiguous(), group=self.group)
+            return self.obs, self.rew, self.term, self.trunc
+        mine = self.counts[self.rank]
+        for k in srcs:
+            self._pad[k][:mine].copy_(srcs[k])
+            dist.all_gather_into_tensor(dsts[k], self._pad[k], group=self.group)
+        keep = torch.cat([torch.arange(r * self.max_count, r * self.max_count + c, device=self.obs.device) for r, c in enumerate(self.counts)])
+        return self.obs[keep], self.rew[keep], self.term[keep], self.trunc[keep]

@@ -1,0 +1,70 @@
+"""PufferLib-shaped env class over the C-ABI.
+
+Mirrors the shape of a PufferLib ocean env's Python side — flat shared buffers
+``observations / actions / rewards / terminals / truncations``, ``num_agents``,
+``single_observation_space`` / ``single_action_space``, ``reset(seed)``,
+``step(actions)`` returning ``(obs, rewards, terminals, truncations, infos)``
+with the aggregated log appended to ``infos`` every ``log_interval`` steps,
+``close()``. The upstream class cannot be cited or import-tested: the
+``pufferlib`` submodule is empty in the reference snapshot
+(``/root/reference/.gitmodules:1-3``); the drop-in claim is to that extent
+unverified.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import abi, binding
+
+
+@dataclass(frozen=True)
+class Box:
+    """Minimal stand-in for gymnasium.spaces.Box (gymnasium is not a dependency)."""
+    low: float
+    high: float
+    shape: tuple
+    dtype: type = np.float32
+
+
+class Drone:
+    def __init__(self, num_envs=1024, task="hover", device=None, seed=0, log_interval=128, **config):
+        task_id = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT}[task] if isinstance(task, str) else int(task)
+        self.vec = binding.DroneVec(num_envs, seed=seed, task=task_id, device=device, **config)
+        self.num_agents = self.vec.num_envs
+        self.single_observation_space = Box(-np.inf, np.inf, (abi.OBS_DIM,))
+        self.single_action_space = Box(-1.0, 1.0, (abi.ACT_DIM,))
+        self.log_interval = int(log_interval)
+        self.seed = seed
+        self.tick = 0
+
+    # the shared buffers, exactly the arrays / tensors the C side reads and writes
+    observations = property(lambda self: self.vec.observations)
+    actions = property(lambda self: self.vec.actions)
+    rewards = property(lambda self: self.vec.rewards)
+    terminals = property(lambda self: self.vec.terminals)
+    truncations = property(lambda self: self.vec.truncations)
+
+    def reset(self, seed=None):
+        if seed is not None:
+            self.seed = seed
+        self.vec.reset(self.seed)
+        self.tick = 0
+        return self.observations, []
+
+    def step(self, actions):
+        if actions is not self.vec.actions:
+            if self.vec.torch_device is None:
+                self.vec.actions[:] = actions
+            else:
+                self.vec.actions.copy_(actions, non_blocking=True)
+        self.vec.step()
+        self.tick += 1
+        infos = []
+        if self.log_interval and self.tick % self.log_interval == 0:
+            log = self.vec.log()
+            if log["n"] > 0:
+                infos.append(log)
+        return self.observations, self.rewards, self.terminals, self.truncations, infos
+
+    def close(self):
+        self.vec.close()

