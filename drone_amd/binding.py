@@ -65,6 +65,15 @@ def _ptr(x):
     return x.data_ptr() if _is_torch(x) else x.ctypes.data
 
 
+def load_variant(path):
+    """Bind another build of the library (tuning A/B only): returns its function table."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    return abi.bind(C.CDLL(path))
+
+
 class DroneVec:
     """One shard of envs on one GPU.
 
@@ -74,8 +83,9 @@ class DroneVec:
     stream for that device.
     """
 
-    def __init__(self, num_envs, seed=0, task=abi.TASK_HOVER, device=None, cfg=None, **overrides):
+    def __init__(self, num_envs, seed=0, task=abi.TASK_HOVER, device=None, cfg=None, fns=None, **overrides):
         load()
+        self._f = _fns if fns is None else fns
         self.num_envs = int(num_envs)
         n = self.num_envs
         self.cfg = cfg if cfg is not None else default_config(task, **overrides)
@@ -102,11 +112,11 @@ class DroneVec:
             self.rewards = torch.zeros(n, dtype=torch.float32, device=dev)
             self.terminals = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.truncations = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self._h = _fns["drone_vec_init"](
+        self._h = self._f["drone_vec_init"](
             _ptr(self.observations), _ptr(self.actions), _ptr(self.rewards), _ptr(self.terminals), _ptr(self.truncations),
             n, seed, C.byref(self.cfg))
         if not self._h:
-            raise RuntimeError("drone_vec_init failed: " + last_error())
+            raise RuntimeError("drone_vec_init failed: " + self._f["drone_last_error"]().decode())
         if self.torch_device is not None:
             self.use_torch_stream()
 
@@ -115,33 +125,33 @@ class DroneVec:
         import torch
 
         s = torch.cuda.current_stream(self.torch_device)
-        self._check(_fns["drone_vec_set_stream"](self._h, C.c_void_p(s.cuda_stream)))
+        self._check(self._f["drone_vec_set_stream"](self._h, C.c_void_p(s.cuda_stream)))
 
     def sync(self):
-        self._check(_fns["drone_vec_sync"](self._h))
+        self._check(self._f["drone_vec_sync"](self._h))
 
     def _check(self, rc):
         if rc != 0:
-            raise RuntimeError("libdrone_hip: " + last_error())
+            raise RuntimeError("libdrone_hip: " + self._f["drone_last_error"]().decode())
 
     # -- the path --
     def reset(self, seed=0):
-        _fns["drone_vec_reset"](self._h, seed)
+        self._f["drone_vec_reset"](self._h, seed)
 
     def step(self):
-        _fns["drone_vec_step"](self._h)
+        self._f["drone_vec_step"](self._h)
 
     def rollout(self, horizon):
-        _fns["drone_vec_rollout"](self._h, int(horizon))
+        self._f["drone_vec_rollout"](self._h, int(horizon))
 
     def log(self):
         out = abi.DroneLog()
-        _fns["drone_vec_log"](self._h, C.byref(out))
+        self._f["drone_vec_log"](self._h, C.byref(out))
         return out.as_dict()
 
     def close(self):
         if getattr(self, "_h", None):
-            _fns["drone_vec_close"](self._h)
+            self._f["drone_vec_close"](self._h)
             self._h = None
 
     def __del__(self):
@@ -153,39 +163,39 @@ class DroneVec:
     # -- around the path --
     @property
     def gstep(self):
-        return _fns["drone_vec_gstep"](self._h)
+        return self._f["drone_vec_gstep"](self._h)
 
     def bind_actions(self, actions):
-        self._check(_fns["drone_vec_bind_actions"](self._h, _ptr(actions)))
+        self._check(self._f["drone_vec_bind_actions"](self._h, _ptr(actions)))
         self.actions = actions
 
     def fill_random_actions(self, gstep=None, out=None):
         out = self.actions if out is None else out
         g = self.gstep if gstep is None else gstep
-        self._check(_fns["drone_vec_fill_random_actions"](self._h, _ptr(out), g))
+        self._check(self._f["drone_vec_fill_random_actions"](self._h, _ptr(out), g))
         return out
 
     def get_state(self, first=0, count=None):
         count = self.num_envs - first if count is None else count
         rows = np.zeros(count, dtype=abi.state_row_dtype())
-        self._check(_fns["drone_vec_get_state"](self._h, rows.ctypes.data, first, count))
+        self._check(self._f["drone_vec_get_state"](self._h, rows.ctypes.data, first, count))
         return rows
 
     def set_state(self, rows, first=0):
         rows = np.ascontiguousarray(rows, dtype=abi.state_row_dtype())
-        self._check(_fns["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows)))
+        self._check(self._f["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows)))
 
     def done_list(self):
         ids = np.zeros(self.num_envs, dtype=np.uint32)
-        cnt = _fns["drone_vec_done_list"](self._h, ids.ctypes.data, self.num_envs)
+        cnt = self._f["drone_vec_done_list"](self._h, ids.ctypes.data, self.num_envs)
         if cnt < 0:
-            raise RuntimeError("libdrone_hip: " + last_error())
+            raise RuntimeError("libdrone_hip: " + self._f["drone_last_error"]().decode())
         return ids[:cnt]
 
     def timer_start(self):
-        self._check(_fns["drone_vec_timer_start"](self._h))
+        self._check(self._f["drone_vec_timer_start"](self._h))
 
     def timer_stop(self):
         ms = C.c_float(0)
-        self._check(_fns["drone_vec_timer_stop"](self._h, C.byref(ms)))
+        self._check(self._f["drone_vec_timer_stop"](self._h, C.byref(ms)))
         return ms.value

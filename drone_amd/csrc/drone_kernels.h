@@ -25,7 +25,10 @@ struct DeviceView {
     uint32_t* done_count;// [2] ping-pong by gstep parity, or null
 };
 
-constexpr int kBlock = 256;
+#ifndef DRONE_BLOCK  // workgroup size (tuning knob; multiple of 64)
+#define DRONE_BLOCK 256
+#endif
+constexpr int kBlock = DRONE_BLOCK;
 
 hipError_t launch_reset(const DeviceView& v, hipStream_t s);
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s);

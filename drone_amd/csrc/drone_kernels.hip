@@ -31,6 +31,9 @@
 #ifndef DRONE_PARAMS_IN_SGPR  // 1: constants from the kernarg segment (scalar loads) instead of the LDS block
 #define DRONE_PARAMS_IN_SGPR 0
 #endif
+#ifndef DRONE_OBS_WAVE_SYNC  // 1: order the wave-private LDS tile with wave-scope fences instead of __syncthreads()
+#define DRONE_OBS_WAVE_SYNC 0
+#endif
 #ifndef DRONE_PERSISTENT_BLOCKS_PER_CU  // >0: cap the grid at this many workgroups per CU and loop over chunks
 #define DRONE_PERSISTENT_BLOCKS_PER_CU 0
 #endif
@@ -50,6 +53,15 @@ template <typename T>
 __device__ __forceinline__ void out_store(T* p, const T& v) {
 #if DRONE_NT_STORES
     __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void out_store(float4* p, const float4& v) {
+#if DRONE_NT_STORES
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    f4_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
 #else
     *p = v;
 #endif
@@ -104,7 +116,15 @@ __device__ __forceinline__ void store_obs_wave(float* __restrict__ obs, float4* 
                                                uint32_t wave_base, uint32_t n, uint32_t lane) {
 #pragma unroll
     for (int k = 0; k < kObsVec; k++) tile[lane * kObsVec + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+#if DRONE_OBS_WAVE_SYNC
+    // the tile belongs to this wave alone and a wave's DS operations execute in
+    // order: only the compiler has to be kept from reordering across this point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
     __syncthreads();
+#endif
     const uint32_t rows = n - wave_base < (uint32_t)kWave ? n - wave_base : (uint32_t)kWave;  // caller guarantees wave_base < n for active waves
     float4* dst = reinterpret_cast<float4*>(obs + (size_t)wave_base * DRONE_OBS_DIM);
 #pragma unroll
