@@ -11,9 +11,10 @@ namespace drone {
 
 // Device pointers for one shard of envs.
 struct DeviceView {
-    float4* planes;      // [kNumPlanes][n_pad]
+    float4* planes;      // [kNumPlanes][stride]
     uint32_t n;          // envs on this device
-    uint32_t n_pad;      // plane stride (multiple of kBlock)
+    uint32_t n_pad;      // n rounded up to a whole workgroup: lanes [n, n_pad) exist and hold a valid reset state
+    uint32_t stride;     // float4 elements between consecutive planes (>= n_pad; padded so planes start on different HBM channels)
     const uint32_t* kp;  // KParams in HBM (kParamWords words) — staged to LDS per workgroup
     const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)
     float* obs;          // [n][20]

@@ -18,15 +18,30 @@
 #include "drone_kernels.h"
 #include "drone_lane.hpp"
 
-// ---- tuning knobs (compile-time; defaults are the measured best) ----
+// ---- tuning knobs (compile-time; defaults are the measured best: DESIGN.md "Tuning log", gpurun_out/ab*.txt) ----
 #ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset
 #define DRONE_STEP_MIN_WAVES 0
 #endif
 #ifndef DRONE_OBS_VIA_LDS  // 1: transpose observation rows through LDS; 0: strided per-lane row stores
 #define DRONE_OBS_VIA_LDS 1
 #endif
-#ifndef DRONE_NT_STORES  // 1: non-temporal stores for the outputs nobody on the GPU re-reads
-#define DRONE_NT_STORES 0
+#ifndef DRONE_NT_STORES  // 1: non-temporal stores for the outputs this path never re-reads (obs, rewards): -5 % at equal placement
+#define DRONE_NT_STORES 1
+#endif
+#ifndef DRONE_NT_STATE  // 1: non-temporal loads and stores for the state planes and actions too
+#define DRONE_NT_STATE 0
+#endif
+#ifndef DRONE_NT_ACT  // 1: non-temporal loads for the action rows (read once, never again)
+#define DRONE_NT_ACT 0
+#endif
+#ifndef DRONE_NT_FLAGS  // 1: non-temporal stores for the packed terminal / truncation dwords
+#define DRONE_NT_FLAGS 0
+#endif
+#ifndef DRONE_STEP_MAX_WAVES  // >0: cap waves per SIMD of the per-step kernel (amdgpu_waves_per_eu)
+#define DRONE_STEP_MAX_WAVES 0
+#endif
+#ifndef DRONE_XCD_REMAP  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the envs (a further -3 % with NT stores)
+#define DRONE_XCD_REMAP 1
 #endif
 #ifndef DRONE_PARAMS_IN_SGPR  // 1: constants from the kernarg segment (scalar loads) instead of the LDS block
 #define DRONE_PARAMS_IN_SGPR 0
@@ -67,6 +82,32 @@ __device__ __forceinline__ void out_store(float4* p, const float4& v) {
 #endif
 }
 
+typedef float f4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 state_load(const float4* p) {
+#if DRONE_NT_STATE
+    const f4_t x = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+    return make_float4(x.x, x.y, x.z, x.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float4 act_load(const float4* p) {
+#if DRONE_NT_ACT
+    const f4_t x = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+    return make_float4(x.x, x.y, x.z, x.w);
+#else
+    return state_load(p);
+#endif
+}
+__device__ __forceinline__ void state_store(float4* p, const float4& v) {
+#if DRONE_NT_STATE
+    f4_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // ---- constants: HBM -> LDS, once per workgroup ----
 __device__ __forceinline__ void stage_params(KParams& sp, const uint32_t* __restrict__ kp) {
     if (threadIdx.x < kParamWords) reinterpret_cast<uint32_t*>(&sp)[threadIdx.x] = kp[threadIdx.x];
@@ -76,12 +117,12 @@ __device__ __forceinline__ void stage_params(KParams& sp, const uint32_t* __rest
 // ---- plane <-> register marshalling ----
 template <int TASK>
 __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_t np, uint32_t i, Lane& L) {
-    const float4 a = pl[kP0 * np + i];
-    const float4 b = pl[kP1 * np + i];
-    const float4 c = pl[kP2 * np + i];
-    const float4 d = pl[kP3 * np + i];
-    const float4 e = pl[kP4 * np + i];
-    const float4 t = pl[kPT * np + i];
+    const float4 a = state_load(&pl[kP0 * np + i]);
+    const float4 b = state_load(&pl[kP1 * np + i]);
+    const float4 c = state_load(&pl[kP2 * np + i]);
+    const float4 d = state_load(&pl[kP3 * np + i]);
+    const float4 e = state_load(&pl[kP4 * np + i]);
+    const float4 t = state_load(&pl[kPT * np + i]);
     L.s.p[0] = a.x; L.s.p[1] = a.y; L.s.p[2] = a.z; L.s.v[0] = a.w;
     L.s.v[1] = b.x; L.s.v[2] = b.y; L.s.q[0] = b.z; L.s.q[1] = b.w;
     L.s.q[2] = c.x; L.s.q[3] = c.y; L.s.o[0] = c.z; L.s.o[1] = c.w;
@@ -89,7 +130,7 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
     L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
     L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
     if (TASK == DRONE_TASK_WAYPOINT) {
-        const float4 w = pl[kPW * np + i];
+        const float4 w = state_load(&pl[kPW * np + i]);
         L.wind[0] = w.x; L.wind[1] = w.y; L.wind[2] = w.z;
     } else {
         L.wind[0] = L.wind[1] = L.wind[2] = 0.0f;
@@ -98,13 +139,13 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
 
 template <int TASK>
 __device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np, uint32_t i, const Lane& L, bool target_changed) {
-    pl[kP0 * np + i] = make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]);
-    pl[kP1 * np + i] = make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]);
-    pl[kP2 * np + i] = make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]);
-    pl[kP3 * np + i] = make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]);
-    pl[kP4 * np + i] = make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count));
-    if (target_changed) pl[kPT * np + i] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
-    if (TASK == DRONE_TASK_WAYPOINT) pl[kPW * np + i] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
+    state_store(&pl[kP0 * np + i], make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]));
+    state_store(&pl[kP1 * np + i], make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]));
+    state_store(&pl[kP2 * np + i], make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]));
+    state_store(&pl[kP3 * np + i], make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]));
+    state_store(&pl[kP4 * np + i], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
+    if (target_changed) state_store(&pl[kPT * np + i], make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode)));
+    if (TASK == DRONE_TASK_WAYPOINT) state_store(&pl[kPW * np + i], make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f));
 }
 
 // ---- wave-cooperative outputs ----
@@ -141,7 +182,12 @@ __device__ __forceinline__ void store_flags_wave(unsigned char* __restrict__ dst
     if (aligned4 && wave_base + kWave <= n) {
         if (lane < 16) {
             const uint32_t nib = (uint32_t)(mask >> (4u * lane)) & 0xFu;
-            reinterpret_cast<uint32_t*>(dst + wave_base)[lane] = (nib * 0x00204081u) & 0x01010101u;
+            const uint32_t packed = (nib * 0x00204081u) & 0x01010101u;
+#if DRONE_NT_FLAGS
+            __builtin_nontemporal_store(packed, &reinterpret_cast<uint32_t*>(dst + wave_base)[lane]);
+#else
+            reinterpret_cast<uint32_t*>(dst + wave_base)[lane] = packed;
+#endif
         }
     } else if (i < n) {
         dst[i] = flag ? 1 : 0;
@@ -168,7 +214,7 @@ struct StepArgs {
 // One 256-drone chunk of the per-step path.
 template <int TASK, bool COMPACT>
 __device__ __forceinline__ void step_chunk(const StepArgs& a, const KParams& sp, float4 (*obs_tile)[kWave * kObsVec], uint32_t chunk) {
-    const uint32_t n = a.v.n, np = a.v.n_pad;
+    const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t i = chunk * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
@@ -180,7 +226,7 @@ __device__ __forceinline__ void step_chunk(const StepArgs& a, const KParams& sp,
     load_lane<TASK>(a.v.planes, np, i, L);
     float act[4];
     {
-        const float4 av = valid ? reinterpret_cast<const float4*>(a.v.act)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 av = valid ? act_load(&reinterpret_cast<const float4*>(a.v.act)[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         act[0] = av.x; act[1] = av.y; act[2] = av.z; act[3] = av.w;
     }
     const uint32_t env = sp.env_offset + i;
@@ -239,9 +285,14 @@ __device__ __forceinline__ void step_chunk(const StepArgs& a, const KParams& sp,
 #else
 #define DRONE_STEP_BOUNDS __launch_bounds__(kBlock)
 #endif
+#if DRONE_STEP_MAX_WAVES > 0
+#define DRONE_STEP_WAVES __attribute__((amdgpu_waves_per_eu(1, DRONE_STEP_MAX_WAVES)))
+#else
+#define DRONE_STEP_WAVES
+#endif
 
 template <int TASK, bool COMPACT>
-__global__ DRONE_STEP_BOUNDS void drone_step_kernel(StepArgs a) {
+__global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a) {
 #if DRONE_OBS_VIA_LDS
     __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
 #else
@@ -261,6 +312,12 @@ __global__ DRONE_STEP_BOUNDS void drone_step_kernel(StepArgs a) {
         __syncthreads();  // the tile is reused by the next chunk
 #endif
     }
+#elif DRONE_XCD_REMAP
+    {   // bijective for any grid size (cdna_hip_programming.md §5 "XCD swizzle must be bijective")
+        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        const uint32_t chunk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
+        step_chunk<TASK, COMPACT>(a, sp, obs_tile, chunk);
+    }
 #else
     step_chunk<TASK, COMPACT>(a, sp, obs_tile, blockIdx.x);
 #endif
@@ -273,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     __shared__ KParams sp;
     __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
     stage_params(sp, a.v.kp);
-    const uint32_t n = a.v.n, np = a.v.n_pad;
+    const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
@@ -306,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint3
     __shared__ KParams sp;
     __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
     stage_params(sp, a.v.kp);
-    const uint32_t n = a.v.n, np = a.v.n_pad;
+    const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
@@ -454,7 +511,7 @@ hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid
     int g = (int)grid_for(v.n);
     if (g > max_grid) g = max_grid;
     *grid_out = g;
-    drone_log_reduce_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(v.planes, v.n, v.n_pad, partials);
+    drone_log_reduce_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(v.planes, v.n, v.stride, partials);
     return hipGetLastError();
 }
 

@@ -54,6 +54,7 @@ struct DroneVec {
     uint32_t gstep;
     int n;
     uint32_t n_pad;
+    uint32_t stride;
     int device;
     bool host_buffers;
     // caller buffers (host or device, per cfg.buffer_kind)
@@ -121,6 +122,16 @@ bool device_to_host_outputs(DroneVec* v) {
     HIP_TRY(hipMemcpyAsync(v->u_trunc, v->d_trunc, n, hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
     return true;
+}
+
+// Plane stride padding, in float4 elements. With a power-of-two env count the
+// planes would otherwise sit exactly 2^k bytes apart and the same env's 16-B
+// slot in every plane would map to the same HBM channel. DRONE_PLANE_PAD
+// overrides the default for tuning experiments.
+uint32_t plane_pad_elems() {
+    const char* e = getenv("DRONE_PLANE_PAD");
+    if (e && *e) return (uint32_t)strtoul(e, nullptr, 10);
+    return 0;
 }
 
 void try_register(DroneVec* v, int slot, void* p, size_t bytes) {
@@ -194,6 +205,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->seed = seed;
     v->n = num_envs;
     v->n_pad = (uint32_t)((num_envs + kBlock - 1) / kBlock) * kBlock;
+    v->stride = v->n_pad + plane_pad_elems();
     v->device = cfg->device;
     v->host_buffers = cfg->buffer_kind == DRONE_BUFFERS_HOST;
     v->u_obs = observations; v->u_act = actions; v->u_rew = rewards; v->u_term = terminals; v->u_trunc = truncations;
@@ -205,8 +217,8 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->own_stream = true;
     INIT_TRY(hipEventCreate(&v->ev0));
     INIT_TRY(hipEventCreate(&v->ev1));
-    INIT_TRY(hipMalloc((void**)&v->dv.planes, sizeof(float4) * (size_t)kNumPlanes * v->n_pad));
-    INIT_TRY(hipMemsetAsync(v->dv.planes, 0, sizeof(float4) * (size_t)kNumPlanes * v->n_pad, v->stream));
+    INIT_TRY(hipMalloc((void**)&v->dv.planes, sizeof(float4) * (size_t)kNumPlanes * v->stride));
+    INIT_TRY(hipMemsetAsync(v->dv.planes, 0, sizeof(float4) * (size_t)kNumPlanes * v->stride, v->stream));
     INIT_TRY(hipMalloc((void**)&v->d_kp, sizeof(KParams)));
     INIT_TRY(hipMalloc((void**)&v->d_partials, sizeof(double) * 6 * kLogMaxGrid));
     INIT_TRY(hipHostMalloc((void**)&v->h_partials, sizeof(double) * 6 * kLogMaxGrid, hipHostMallocDefault));
@@ -237,6 +249,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     }
     v->dv.n = (uint32_t)num_envs;
     v->dv.n_pad = v->n_pad;
+    v->dv.stride = v->stride;
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
@@ -366,7 +379,7 @@ int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) 
     if (!set_device(v)) return -1;
     std::vector<float4> tmp((size_t)kNumPlanes * count);
     for (int p = 0; p < kNumPlanes; p++)
-        HIP_TRY(hipMemcpyAsync(tmp.data() + (size_t)p * count, v->dv.planes + (size_t)p * v->n_pad + first, sizeof(float4) * count, hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipMemcpyAsync(tmp.data() + (size_t)p * count, v->dv.planes + (size_t)p * v->stride + first, sizeof(float4) * count, hipMemcpyDeviceToHost, v->stream), return -1);
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     auto u = [](float f) { uint32_t x; memcpy(&x, &f, 4); return x; };
     for (int i = 0; i < count; i++) {
@@ -405,7 +418,7 @@ int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int c
         tmp[(size_t)kL1 * count + i] = make_float4(r.n_sum, r.oob_sum, 0.0f, 0.0f);
     }
     for (int p = 0; p < kNumPlanes; p++)
-        HIP_TRY(hipMemcpyAsync(v->dv.planes + (size_t)p * v->n_pad + first, tmp.data() + (size_t)p * count, sizeof(float4) * count, hipMemcpyHostToDevice, v->stream), return -1);
+        HIP_TRY(hipMemcpyAsync(v->dv.planes + (size_t)p * v->stride + first, tmp.data() + (size_t)p * count, sizeof(float4) * count, hipMemcpyHostToDevice, v->stream), return -1);
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     return 0;
 }

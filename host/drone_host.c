@@ -1,0 +1,81 @@
+/*
+ * drone_host.c — plain-C host of the drone env, the way a C vec-env worker
+ * would drive it: caller-owned host buffers, init / reset / step / log / close
+ * through include/drone_vec.h, nothing else. (BASELINE.json north_star: "host
+ * side stays C calling HIP through a thin C-ABI".) No HIP headers here: the
+ * device is entirely behind the C-ABI.
+ *
+ *   drone_host [--envs N] [--steps K] [--task 0|1] [--rollout T] [--seed S]
+ *
+ * Prints env-steps/s for (a) per-step calls with host buffers — every step
+ * pays H2D actions + D2H observations/rewards/flags over PCIe — and (b) the
+ * fused rollout, which crosses PCIe once per T steps.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "drone_vec.h"
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char** argv) {
+    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128;
+    unsigned long long seed = 0;
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--envs")) envs = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--task")) task = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--rollout")) rollout = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], NULL, 10);
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    float* obs = (float*)malloc(sizeof(float) * (size_t)envs * DRONE_OBS_DIM);
+    float* act = (float*)malloc(sizeof(float) * (size_t)envs * DRONE_ACT_DIM);
+    float* rew = (float*)malloc(sizeof(float) * (size_t)envs);
+    unsigned char* term = (unsigned char*)malloc((size_t)envs);
+    unsigned char* trunc = (unsigned char*)malloc((size_t)envs);
+    if (!obs || !act || !rew || !term || !trunc) { fprintf(stderr, "out of memory\n"); return 1; }
+
+    DroneConfig cfg;
+    drone_config_default(&cfg, task);
+    cfg.buffer_kind = DRONE_BUFFERS_HOST;
+    DroneVec* v = drone_vec_init(obs, act, rew, term, trunc, envs, seed, &cfg);
+    if (!v) { fprintf(stderr, "drone_vec_init failed: %s\n", drone_last_error()); return 1; }
+    drone_vec_reset(v, seed);
+
+    /* (a) per-step, host buffers: the random policy stands in for the caller's policy */
+    for (int t = 0; t < 10; t++) { drone_vec_fill_random_actions(v, act, drone_vec_gstep(v)); drone_vec_step(v); }
+    double t0 = now_s();
+    long dones = 0;
+    for (int t = 0; t < steps; t++) {
+        drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
+        drone_vec_step(v);
+        for (int i = 0; i < envs; i += 4096) dones += term[i] | trunc[i]; /* touch the outputs */
+    }
+    double el = now_s() - t0;
+    printf("{\"mode\": \"per-step host buffers (PCIe inclusive)\", \"envs\": %d, \"steps\": %d, \"env_steps_per_s\": %.4g, \"ms_per_step\": %.4f}\n",
+           envs, steps, (double)envs * steps / el, el * 1e3 / steps);
+
+    /* (b) fused rollout: PCIe once per horizon */
+    drone_vec_rollout(v, rollout);
+    int reps = steps / rollout > 0 ? steps / rollout : 1;
+    t0 = now_s();
+    for (int r = 0; r < reps; r++) drone_vec_rollout(v, rollout);
+    el = now_s() - t0;
+    printf("{\"mode\": \"fused rollout, host buffers at the horizon\", \"envs\": %d, \"horizon\": %d, \"launches\": %d, \"env_steps_per_s\": %.4g, \"ms_per_launch\": %.4f}\n",
+           envs, rollout, reps, (double)envs * rollout * reps / el, el * 1e3 / reps);
+
+    DroneLog log;
+    drone_vec_log(v, &log);
+    printf("{\"log\": {\"n\": %.0f, \"episode_return\": %.5g, \"episode_length\": %.5g, \"score\": %.5g, \"oob\": %.5g}, \"sampled_dones\": %ld}\n",
+           log.n, log.episode_return, log.episode_length, log.score, log.oob, dones);
+    drone_vec_close(v);
+    free(obs); free(act); free(rew); free(term); free(trunc);
+    return 0;
+}

@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""A/B the per-step kernel across builds of the library in ONE process with
-interleaved rounds (cdna_hip_programming.md §5.4 rule 24): separate processes
-differ by more than the variants do. Run on the GPU box.
+"""A/B the per-step kernel across builds / init-time settings of the library in
+ONE process with interleaved rounds (cdna_hip_programming.md §5.4 rule 24).
 
-  python tools/ab_step.py [--envs N] [--task hover] [--rounds 12] [--steps 200] name=-Dflags ...
+Memory placement alone moves this HBM-bound kernel by ±6 % (identical code,
+different allocations: gpurun_out/ab3.txt), so every variant is created, timed
+and CLOSED in turn: the allocators hand the next variant the same blocks and
+the comparison is at equal placement. `--fresh` keeps all variants alive
+instead (different placements; shows the spread).
+
+  python tools/ab_step.py [--envs N] [--rounds 8] [--steps 200] "name=-Dflags;ENV=val,ENV2=val" ...
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -20,10 +26,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=1 << 20)
     ap.add_argument("--task", default="hover")
-    ap.add_argument("--rounds", type=int, default=12)
+    ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--mode", default="step", choices=["step", "rollout"])
     ap.add_argument("--horizon", type=int, default=128)
+    ap.add_argument("--fresh", action="store_true")
+    ap.add_argument("--ring", type=int, default=4)
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -31,42 +39,65 @@ def main():
     from drone_amd import abi, binding
 
     task = abi.TASK_HOVER if a.task == "hover" else abi.TASK_WAYPOINT
-    vecs = {}
+    specs = {}
     for spec in a.variants:
-        name, _, flags = spec.partition("=")
-        lib = f"/tmp/ab_{name}.so"
-        r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "drone_amd", "csrc"), "-B", f"OUT={lib}", f"EXTRA={flags}"],
-                           capture_output=True, text=True)
-        if r.returncode != 0:
-            print(name, "BUILD FAILED", r.stderr[-400:])
-            continue
-        fns = binding.load_variant(lib)
+        name, _, rest = spec.partition("=")
+        flags, _, envs = rest.partition(";")
+        lib = f"/tmp/ab_{abs(hash(flags)) % 10**8}.so"
+        if not os.path.exists(lib):
+            r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "drone_amd", "csrc"), "-B", f"OUT={lib}", f"EXTRA={flags}"],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                print(name, "BUILD FAILED", r.stderr[-400:])
+                continue
+        specs[name] = (binding.load_variant(lib), dict(kv.split("=", 1) for kv in filter(None, envs.split(","))), rest)
+
+    def make(name):
+        fns, envs, _ = specs[name]
+        os.environ.update(envs)
         v = binding.DroneVec(a.envs, seed=0, task=task, device="cuda:0", fns=fns)
+        for k in envs:
+            os.environ.pop(k, None)
         v.reset(0)
-        ring = [torch.empty_like(v.actions) for _ in range(4)]
+        ring = [torch.empty_like(v.actions) for _ in range(int(envs.get('RING', a.ring)))]
         for k, r_ in enumerate(ring):
             v.fill_random_actions(gstep=k, out=r_)
-        vecs[name] = (v, ring, flags)
-    times = {k: [] for k in vecs}
-    for rnd in range(a.rounds + 1):
-        for name, (v, ring, _) in vecs.items():
+        return v, ring
+
+    def timeit(v, ring):
+        if a.mode == "step":
+            for k in range(20):
+                v.bind_actions(ring[k % len(ring)])
+                v.step()
             torch.cuda.synchronize()
             v.timer_start()
-            if a.mode == "step":
-                for k in range(a.steps):
-                    v.bind_actions(ring[k % len(ring)])
-                    v.step()
-                per = v.timer_stop() * 1e3 / a.steps
+            for k in range(a.steps):
+                v.bind_actions(ring[k % len(ring)])
+                v.step()
+            return v.timer_stop() * 1e3 / a.steps
+        v.rollout(a.horizon)
+        torch.cuda.synchronize()
+        v.timer_start()
+        v.rollout(a.horizon)
+        return v.timer_stop() * 1e3
+
+    times = {k: [] for k in specs}
+    live = {k: make(k) for k in specs} if a.fresh else None
+    for rnd in range(a.rounds):
+        for name in specs:
+            if a.fresh:
+                times[name].append(timeit(*live[name]))
             else:
-                v.rollout(a.horizon)
-                per = v.timer_stop() * 1e3
-            if rnd > 0:
-                times[name].append(per)
+                v, ring = make(name)
+                times[name].append(timeit(v, ring))
+                v.close()
+                del v, ring
+                gc.collect()
     base = None
     for name, ts in times.items():
-        med, mn = statistics.median(ts), min(ts)
+        med = statistics.median(ts)
         base = base or med
-        print(json.dumps({"variant": name, "flags": vecs[name][2], "median_us": round(med, 2), "min_us": round(mn, 2),
+        print(json.dumps({"variant": name, "spec": specs[name][2], "median_us": round(med, 2), "min_us": round(min(ts), 2),
                           "max_us": round(max(ts), 2), "vs_first": round(med / base, 4)}))
 
 
