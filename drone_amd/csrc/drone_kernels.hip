@@ -2,15 +2,22 @@
 //
 // One lane = one drone. State lives in HBM as float4 planes (drone_params.hpp),
 // so every state access is a 16-B-per-lane, 1-KiB-per-wave coalesced
-// global_load/store_dwordx4. The per-env constants block (KParams, 48 words)
-// is staged into LDS once per workgroup and read by broadcast. Observation
-// rows ([N][20] AoS, what a vec-env consumer expects) are transposed through a
-// wave-private LDS tile so they leave as five fully coalesced 1-KiB stores per
-// wave instead of 64 strided 80-B rows. Terminal / truncation bytes are built
-// from the wave's __ballot mask (16 lanes store 4 packed bytes each), and the
-// optional done-id list is compacted with ballot + mbcnt + one atomic per wave.
+// global_load/store_dwordx4. Outputs leave in whole cache lines and
+// non-temporally (nothing on the GPU re-reads them in this path):
+//   * observation rows ([N][20] AoS, what a vec-env consumer expects) are
+//     transposed through a wave-private LDS tile, so a wave emits five 1-KiB
+//     stores instead of 64 strided 80-B rows (2.5x on the whole kernel);
+//   * terminal / truncation bytes are built from the waves' __ballot masks,
+//     gathered per workgroup in LDS and written as 16-B pieces by the first 32
+//     lanes — partial-line dword stores of the same bytes cost 11 % of the kernel;
+//   * the optional done-id list is compacted with ballot + mbcnt + one atomic
+//     per wave.
+// The 48-word constants block (KParams) reaches the lanes either through the
+// kernarg segment (scalar loads -> SGPR operands; default, measured faster) or
+// staged through LDS by each workgroup (DRONE_PARAMS_IN_LDS=1).
 //
-// The path is elementwise: no MFMA. Roofline = HBM.
+// The path is elementwise: no MFMA. Roofline = HBM for the per-step kernel,
+// f32 VALU for the fused rollout.
 // Implements SPEC.md; reference file:line cannot be cited (no source in
 // /root/reference — .gitmodules:1-3).
 #include <hip/hip_runtime.h>
@@ -18,39 +25,22 @@
 #include "drone_kernels.h"
 #include "drone_lane.hpp"
 
-// ---- tuning knobs (compile-time; defaults are the measured best: DESIGN.md "Tuning log", gpurun_out/ab*.txt) ----
+// ---- tuning knobs (compile-time). Defaults are the measured best at equal
+// memory placement: DESIGN.md "Tuning log", profiles/r01_ab_*.txt ----
+#ifndef DRONE_PARAMS_IN_LDS  // 1: stage KParams HBM -> LDS per workgroup; 0: kernarg scalar loads (-2.4 % step, -13 % rollout)
+#define DRONE_PARAMS_IN_LDS 0
+#endif
+#ifndef DRONE_NT_STORES  // 1: non-temporal stores for observations / rewards / flags (-5 % step)
+#define DRONE_NT_STORES 1
+#endif
+#ifndef DRONE_XCD_REMAP  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the envs (-3 % step)
+#define DRONE_XCD_REMAP 1
+#endif
 #ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset
 #define DRONE_STEP_MIN_WAVES 0
 #endif
-#ifndef DRONE_OBS_VIA_LDS  // 1: transpose observation rows through LDS; 0: strided per-lane row stores
-#define DRONE_OBS_VIA_LDS 1
-#endif
-#ifndef DRONE_NT_STORES  // 1: non-temporal stores for the outputs this path never re-reads (obs, rewards): -5 % at equal placement
-#define DRONE_NT_STORES 1
-#endif
-#ifndef DRONE_NT_STATE  // 1: non-temporal loads and stores for the state planes and actions too
-#define DRONE_NT_STATE 0
-#endif
-#ifndef DRONE_NT_ACT  // 1: non-temporal loads for the action rows (read once, never again)
-#define DRONE_NT_ACT 0
-#endif
-#ifndef DRONE_NT_FLAGS  // 1: non-temporal stores for the packed terminal / truncation dwords
-#define DRONE_NT_FLAGS 0
-#endif
 #ifndef DRONE_STEP_MAX_WAVES  // >0: cap waves per SIMD of the per-step kernel (amdgpu_waves_per_eu)
 #define DRONE_STEP_MAX_WAVES 0
-#endif
-#ifndef DRONE_XCD_REMAP  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the envs (a further -3 % with NT stores)
-#define DRONE_XCD_REMAP 1
-#endif
-#ifndef DRONE_PARAMS_IN_SGPR  // 1: constants from the kernarg segment (scalar loads) instead of the LDS block
-#define DRONE_PARAMS_IN_SGPR 0
-#endif
-#ifndef DRONE_OBS_WAVE_SYNC  // 1: order the wave-private LDS tile with wave-scope fences instead of __syncthreads()
-#define DRONE_OBS_WAVE_SYNC 0
-#endif
-#ifndef DRONE_PERSISTENT_BLOCKS_PER_CU  // >0: cap the grid at this many workgroups per CU and loop over chunks
-#define DRONE_PERSISTENT_BLOCKS_PER_CU 0
 #endif
 
 namespace drone {
@@ -59,13 +49,18 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kObsVec = DRONE_OBS_DIM / 4;  // float4 per obs row = 5
+constexpr int kObsVec = DRONE_OBS_DIM / 4;     // float4 per observation row = 5
+constexpr int kFlagLanes = kBlock / 16;        // lanes that write one flag array of a workgroup, 16 B each
+static_assert(kBlock % kWave == 0 && 2 * kFlagLanes <= kWave, "workgroup must be 64..512 threads");
+
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-template <typename T>
-__device__ __forceinline__ void out_store(T* p, const T& v) {
+// stores of data this path never reads back
+__device__ __forceinline__ void out_store(float* p, float v) {
 #if DRONE_NT_STORES
     __builtin_nontemporal_store(v, p);
 #else
@@ -74,55 +69,29 @@ __device__ __forceinline__ void out_store(T* p, const T& v) {
 }
 __device__ __forceinline__ void out_store(float4* p, const float4& v) {
 #if DRONE_NT_STORES
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    f4_t x = {v.x, v.y, v.z, v.w};
+    const f4_t x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
 #else
     *p = v;
 #endif
 }
-
-typedef float f4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 state_load(const float4* p) {
-#if DRONE_NT_STATE
-    const f4_t x = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
-    return make_float4(x.x, x.y, x.z, x.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ float4 act_load(const float4* p) {
-#if DRONE_NT_ACT
-    const f4_t x = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
-    return make_float4(x.x, x.y, x.z, x.w);
-#else
-    return state_load(p);
-#endif
-}
-__device__ __forceinline__ void state_store(float4* p, const float4& v) {
-#if DRONE_NT_STATE
-    f4_t x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
+__device__ __forceinline__ void out_store(u4_t* p, const u4_t& v) {
+#if DRONE_NT_STORES
+    __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
-}
-
-// ---- constants: HBM -> LDS, once per workgroup ----
-__device__ __forceinline__ void stage_params(KParams& sp, const uint32_t* __restrict__ kp) {
-    if (threadIdx.x < kParamWords) reinterpret_cast<uint32_t*>(&sp)[threadIdx.x] = kp[threadIdx.x];
-    __syncthreads();
 }
 
 // ---- plane <-> register marshalling ----
 template <int TASK>
 __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_t np, uint32_t i, Lane& L) {
-    const float4 a = state_load(&pl[kP0 * np + i]);
-    const float4 b = state_load(&pl[kP1 * np + i]);
-    const float4 c = state_load(&pl[kP2 * np + i]);
-    const float4 d = state_load(&pl[kP3 * np + i]);
-    const float4 e = state_load(&pl[kP4 * np + i]);
-    const float4 t = state_load(&pl[kPT * np + i]);
+    const float4 a = pl[kP0 * np + i];
+    const float4 b = pl[kP1 * np + i];
+    const float4 c = pl[kP2 * np + i];
+    const float4 d = pl[kP3 * np + i];
+    const float4 e = pl[kP4 * np + i];
+    const float4 t = pl[kPT * np + i];
     L.s.p[0] = a.x; L.s.p[1] = a.y; L.s.p[2] = a.z; L.s.v[0] = a.w;
     L.s.v[1] = b.x; L.s.v[2] = b.y; L.s.q[0] = b.z; L.s.q[1] = b.w;
     L.s.q[2] = c.x; L.s.q[3] = c.y; L.s.o[0] = c.z; L.s.o[1] = c.w;
@@ -130,7 +99,7 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
     L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
     L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
     if (TASK == DRONE_TASK_WAYPOINT) {
-        const float4 w = state_load(&pl[kPW * np + i]);
+        const float4 w = pl[kPW * np + i];
         L.wind[0] = w.x; L.wind[1] = w.y; L.wind[2] = w.z;
     } else {
         L.wind[0] = L.wind[1] = L.wind[2] = 0.0f;
@@ -139,147 +108,113 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
 
 template <int TASK>
 __device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np, uint32_t i, const Lane& L, bool target_changed) {
-    state_store(&pl[kP0 * np + i], make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]));
-    state_store(&pl[kP1 * np + i], make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]));
-    state_store(&pl[kP2 * np + i], make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]));
-    state_store(&pl[kP3 * np + i], make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]));
-    state_store(&pl[kP4 * np + i], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
-    if (target_changed) state_store(&pl[kPT * np + i], make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode)));
-    if (TASK == DRONE_TASK_WAYPOINT) state_store(&pl[kPW * np + i], make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f));
+    pl[kP0 * np + i] = make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]);
+    pl[kP1 * np + i] = make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]);
+    pl[kP2 * np + i] = make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]);
+    pl[kP3 * np + i] = make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]);
+    pl[kP4 * np + i] = make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count));
+    if (target_changed) pl[kPT * np + i] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
+    if (TASK == DRONE_TASK_WAYPOINT) pl[kPW * np + i] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
 }
 
-// ---- wave-cooperative outputs ----
-
-// Observation rows of one wave: registers -> wave-private LDS tile (row-major,
-// ds_write_b128, conflict-free at the 80-B row stride) -> read back flat ->
-// global_store_dwordx4 at consecutive 16-B slots: 5 × 1 KiB per wave.
-__device__ __forceinline__ void store_obs_wave(float* __restrict__ obs, float4* tile, const float (&o)[DRONE_OBS_DIM],
-                                               uint32_t wave_base, uint32_t n, uint32_t lane) {
-#pragma unroll
-    for (int k = 0; k < kObsVec; k++) tile[lane * kObsVec + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-#if DRONE_OBS_WAVE_SYNC
-    // the tile belongs to this wave alone and a wave's DS operations execute in
-    // order: only the compiler has to be kept from reordering across this point
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-    __syncthreads();
-#endif
-    const uint32_t rows = n - wave_base < (uint32_t)kWave ? n - wave_base : (uint32_t)kWave;  // caller guarantees wave_base < n for active waves
-    float4* dst = reinterpret_cast<float4*>(obs + (size_t)wave_base * DRONE_OBS_DIM);
-#pragma unroll
-    for (int k = 0; k < kObsVec; k++) {
-        const uint32_t j = k * kWave + lane;
-        if (j < rows * kObsVec) out_store(&dst[j], tile[j]);
-    }
-}
-
-// 64 one-byte flags of a wave from its ballot mask: lane l < 16 spreads mask
-// bits 4l..4l+3 into 4 bytes and stores one dword (needs a 4-B aligned base).
-__device__ __forceinline__ void store_flags_wave(unsigned char* __restrict__ dst, uint64_t mask, bool flag, uint32_t wave_base,
-                                                 uint32_t i, uint32_t n, uint32_t lane, bool aligned4) {
-    if (aligned4 && wave_base + kWave <= n) {
-        if (lane < 16) {
-            const uint32_t nib = (uint32_t)(mask >> (4u * lane)) & 0xFu;
-            const uint32_t packed = (nib * 0x00204081u) & 0x01010101u;
-#if DRONE_NT_FLAGS
-            __builtin_nontemporal_store(packed, &reinterpret_cast<uint32_t*>(dst + wave_base)[lane]);
-#else
-            reinterpret_cast<uint32_t*>(dst + wave_base)[lane] = packed;
-#endif
-        }
-    } else if (i < n) {
-        dst[i] = flag ? 1 : 0;
-    }
+// per-env log sums: touched only when an episode ended
+__device__ __forceinline__ void fold_log(float4& l0, float4& l1, const StepOut& out) {
+    l0.x += out.perf; l0.y += out.score; l0.z += out.ep_return; l0.w += out.ep_len;
+    l1.x += 1.0f; l1.y += out.oob ? 1.0f : 0.0f;
 }
 
 struct StepArgs {
     DeviceView v;
     uint32_t gstep;
-    uint32_t flags_aligned;  // bit0: term 4-B aligned, bit1: trunc 4-B aligned
-#if DRONE_PARAMS_IN_SGPR
-    KParams kp_val;          // constants by value: read with scalar loads from the kernarg segment
+    uint32_t flags_aligned;  // bit0: terminals 16-B aligned, bit1: truncations 16-B aligned
+#if !DRONE_PARAMS_IN_LDS
+    KParams kp;              // constants by value: scalar loads from the kernarg segment
 #endif
 };
 
-// Observation rows without the LDS transpose: each lane stores its own 80-B row.
-[[maybe_unused]] __device__ __forceinline__ void store_obs_direct(float* __restrict__ obs, const float (&o)[DRONE_OBS_DIM], uint32_t i, bool valid) {
-    if (!valid) return;
-    float4* dst = reinterpret_cast<float4*>(obs + (size_t)i * DRONE_OBS_DIM);
-#pragma unroll
-    for (int k = 0; k < kObsVec; k++) out_store(&dst[k], make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]));
-}
+// LDS of one workgroup
+struct Shared {
+    float4 obs_tile[kWavesPerBlock][kWave * kObsVec];  // wave-private observation tiles
+    uint64_t masks[2][kWavesPerBlock];                 // ballot masks: [terminal | truncation][wave]
+#if DRONE_PARAMS_IN_LDS
+    KParams kp;
+#endif
+};
 
-// One 256-drone chunk of the per-step path.
-template <int TASK, bool COMPACT>
-__device__ __forceinline__ void step_chunk(const StepArgs& a, const KParams& sp, float4 (*obs_tile)[kWave * kObsVec], uint32_t chunk) {
-    const uint32_t n = a.v.n, np = a.v.stride;
-    const uint32_t i = chunk * kBlock + threadIdx.x;
+#if DRONE_PARAMS_IN_LDS
+#define DRONE_PARAMS(sh, a) stage_params((sh).kp, (a).v.kp)
+__device__ __forceinline__ const KParams& stage_params(KParams& sp, const uint32_t* __restrict__ kp) {
+    if (threadIdx.x < kParamWords) reinterpret_cast<uint32_t*>(&sp)[threadIdx.x] = kp[threadIdx.x];
+    __syncthreads();
+    return sp;
+}
+#else
+#define DRONE_PARAMS(sh, a) ((a).kp)
+#endif
+
+// 4 mask bits -> 4 bytes of 0/1
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return ((nib & 0xFu) * 0x00204081u) & 0x01010101u; }
+
+// The whole workgroup's outputs for its 256 drones: observation rows, rewards
+// are already stored by the caller; here obs + terminal/truncation bytes.
+// Every thread of the workgroup must call this (it contains the barrier).
+__device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, uint32_t flags_aligned, const float (&o)[DRONE_OBS_DIM],
+                                              bool term, bool trunc, uint32_t i, uint32_t block_base) {
+    const uint32_t n = v.n;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t wave_base = i - lane;
     const bool valid = i < n;
-    // planes are padded to n_pad, so loads of the padding lanes are in bounds;
-    // they compute on the reset state and store nothing.
-    Lane L;
-    load_lane<TASK>(a.v.planes, np, i, L);
-    float act[4];
-    {
-        const float4 av = valid ? act_load(&reinterpret_cast<const float4*>(a.v.act)[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        act[0] = av.x; act[1] = av.y; act[2] = av.z; act[3] = av.w;
+    const uint64_t m_term = __ballot(valid && term);
+    const uint64_t m_trunc = __ballot(valid && trunc);
+    if (lane == 0) {
+        sh.masks[0][wave] = m_term;
+        sh.masks[1][wave] = m_trunc;
     }
-    const uint32_t env = sp.env_offset + i;
-    StepOut out;
-    lane_step<TASK>(sp, L, act, env, a.gstep, out);
-    const bool done = valid && (out.oob || out.trunc);
+    float4* tile = sh.obs_tile[wave];
+#pragma unroll
+    for (int k = 0; k < kObsVec; k++)  // row-major [lane][20]: ds_write_b128, conflict-free at the 80-B row stride
+        tile[lane * kObsVec + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    __syncthreads();
 
-    if (valid) {
-        store_lane<TASK>(a.v.planes, np, i, L, out.target_changed);
-        out_store(&a.v.rew[i], out.reward);
-        if (done) {  // rare: fold the finished episode into this env's log sums
-            float4 l0 = a.v.planes[kL0 * np + i];
-            float4 l1 = a.v.planes[kL1 * np + i];
-            l0.x += out.perf; l0.y += out.score; l0.z += out.ep_return; l0.w += out.ep_len;
-            l1.x += 1.0f; l1.y += out.oob ? 1.0f : 0.0f;
-            a.v.planes[kL0 * np + i] = l0;
-            a.v.planes[kL1 * np + i] = l1;
+    if (wave_base < n) {  // read the tile back flat: 5 x 1 KiB contiguous per wave
+        const uint32_t rows = n - wave_base < (uint32_t)kWave ? n - wave_base : (uint32_t)kWave;
+        float4* dst = reinterpret_cast<float4*>(v.obs + (size_t)wave_base * DRONE_OBS_DIM);
+#pragma unroll
+        for (int k = 0; k < kObsVec; k++) {
+            const uint32_t j = k * kWave + lane;
+            if (j < rows * kObsVec) out_store(&dst[j], tile[j]);
         }
     }
 
-    // done-mask work on the wave's ballots
-    const uint64_t m_term = __ballot(valid && out.oob);
-    const uint64_t m_trunc = __ballot(valid && out.trunc);
-    store_flags_wave(a.v.term, m_term, out.oob, wave_base, i, n, lane, a.flags_aligned & 1u);
-    store_flags_wave(a.v.trunc, m_trunc, out.trunc, wave_base, i, n, lane, a.flags_aligned & 2u);
-    if (COMPACT) {
-        const uint64_t m_done = m_term | m_trunc;
-        uint32_t* cnt = a.v.done_count + (a.gstep & 1u);
-        if (chunk == 0 && threadIdx.x == 0) a.v.done_count[(a.gstep + 1u) & 1u] = 0u;  // arm the next step's counter
-        if (m_done != 0) {  // wave-uniform
-            const uint32_t total = (uint32_t)__popcll(m_done);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cnt, total);
-            base = __shfl(base, 0);
-            if (done) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
-                a.v.done_ids[base + rank] = i;
-            }
+    const bool full = block_base + kBlock <= n;  // workgroup-uniform
+    if (full && (flags_aligned & 3u) == 3u) {
+        if (threadIdx.x < 2 * kFlagLanes) {  // lanes 0..15: terminals, 16..31: truncations; 16 drones = 16 B each
+            const uint32_t which = threadIdx.x / kFlagLanes, j = threadIdx.x % kFlagLanes;
+            const uint32_t bits = (uint32_t)(sh.masks[which][j >> 2] >> ((j & 3u) * 16u)) & 0xFFFFu;
+            const u4_t packed = {spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12)};
+            unsigned char* base = which ? v.trunc : v.term;
+            out_store(reinterpret_cast<u4_t*>(base + block_base) + j, packed);
         }
+    } else if (valid) {
+        v.term[i] = term ? 1 : 0;
+        v.trunc[i] = trunc ? 1 : 0;
     }
+}
 
-    float o[DRONE_OBS_DIM];
-    lane_obs(sp, L, o);
-#if DRONE_OBS_VIA_LDS
-    store_obs_wave(a.v.obs, obs_tile[wave], o, wave_base < n ? wave_base : 0u, wave_base < n ? n : 0u, lane);
+// which 256-drone chunk this workgroup owns
+__device__ __forceinline__ uint32_t my_chunk() {
+#if DRONE_XCD_REMAP
+    // Workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 labels the
+    // workgroups that share an XCD (and its L2): give each label one contiguous
+    // eighth of the envs. Bijective for any grid size; a speed choice only.
+    const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
 #else
-    store_obs_direct(a.v.obs, o, i, valid);
+    return blockIdx.x;
 #endif
 }
 
-// =====================================================================
-// per-step kernel (SPEC.md §5): configs 1–4
-// =====================================================================
 #if DRONE_STEP_MIN_WAVES > 0
 #define DRONE_STEP_BOUNDS __launch_bounds__(kBlock, DRONE_STEP_MIN_WAVES)
 #else
@@ -291,66 +226,81 @@ __device__ __forceinline__ void step_chunk(const StepArgs& a, const KParams& sp,
 #define DRONE_STEP_WAVES
 #endif
 
+// =====================================================================
+// per-step kernel (SPEC.md §5): configs 1–4
+// =====================================================================
 template <int TASK, bool COMPACT>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a) {
-#if DRONE_OBS_VIA_LDS
-    __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
-#else
-    float4 (*obs_tile)[kWave * kObsVec] = nullptr;
-#endif
-#if DRONE_PARAMS_IN_SGPR
-    const KParams& sp = a.kp_val;
-#else
-    __shared__ KParams sp;
-    stage_params(sp, a.v.kp);
-#endif
-#if DRONE_PERSISTENT_BLOCKS_PER_CU > 0
-    const uint32_t chunks = (a.v.n + kBlock - 1) / kBlock;
-    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        step_chunk<TASK, COMPACT>(a, sp, obs_tile, chunk);
-#if DRONE_OBS_VIA_LDS
-        __syncthreads();  // the tile is reused by the next chunk
-#endif
+    __shared__ Shared sh;
+    const KParams& P = DRONE_PARAMS(sh, a);
+    const uint32_t n = a.v.n, np = a.v.stride;
+    const uint32_t block_base = my_chunk() * kBlock;
+    const uint32_t i = block_base + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const bool valid = i < n;
+    // lanes [n, n_pad) exist in the planes and hold a valid reset state: they
+    // load and compute like the rest and store nothing.
+    Lane L;
+    load_lane<TASK>(a.v.planes, np, i, L);
+    float act[4];
+    {
+        const float4 av = valid ? reinterpret_cast<const float4*>(a.v.act)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        act[0] = av.x; act[1] = av.y; act[2] = av.z; act[3] = av.w;
     }
-#elif DRONE_XCD_REMAP
-    {   // bijective for any grid size (cdna_hip_programming.md §5 "XCD swizzle must be bijective")
-        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
-        const uint32_t chunk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
-        step_chunk<TASK, COMPACT>(a, sp, obs_tile, chunk);
+    StepOut out;
+    lane_step<TASK>(P, L, act, P.env_offset + i, a.gstep, out);
+    const bool done = valid && (out.oob || out.trunc);
+
+    if (valid) {
+        store_lane<TASK>(a.v.planes, np, i, L, out.target_changed);
+        out_store(&a.v.rew[i], out.reward);
+        if (done) {
+            float4 l0 = a.v.planes[kL0 * np + i], l1 = a.v.planes[kL1 * np + i];
+            fold_log(l0, l1, out);
+            a.v.planes[kL0 * np + i] = l0;
+            a.v.planes[kL1 * np + i] = l1;
+        }
     }
-#else
-    step_chunk<TASK, COMPACT>(a, sp, obs_tile, blockIdx.x);
-#endif
+
+    if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
+        const uint64_t m_done = __ballot(done);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[(a.gstep + 1u) & 1u] = 0u;  // arm the next step's counter
+        if (m_done != 0) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.v.done_count + (a.gstep & 1u), (uint32_t)__popcll(m_done));
+            base = __shfl(base, 0);
+            if (done) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
+                a.v.done_ids[base + rank] = i;
+            }
+        }
+    }
+
+    float o[DRONE_OBS_DIM];
+    lane_obs(P, L, o);
+    write_outputs(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base);
 }
 
 // =====================================================================
-// vec_reset (SPEC.md §6)
+// vec_reset (SPEC.md §6). Grid covers n_pad so the padding lanes are valid too.
 // =====================================================================
 __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
-    __shared__ KParams sp;
-    __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
-    stage_params(sp, a.v.kp);
+    __shared__ Shared sh;
+    const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = threadIdx.x / kWave;
-    const uint32_t wave_base = i - lane;
+    const uint32_t block_base = blockIdx.x * kBlock;
+    const uint32_t i = block_base + threadIdx.x;
     Lane L;
     L.episode = 0u;
-    lane_reset(sp, L, sp.env_offset + i);
-    // every plane, padding lanes included (keeps padding finite)
-    store_lane<DRONE_TASK_WAYPOINT>(a.v.planes, np, i, L, true);
+    lane_reset(P, L, P.env_offset + i);
+    store_lane<DRONE_TASK_WAYPOINT>(a.v.planes, np, i, L, true);  // every plane, wind included
     a.v.planes[kL0 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.v.planes[kL1 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) {
-        a.v.rew[i] = 0.0f;
-        a.v.term[i] = 0;
-        a.v.trunc[i] = 0;
-    }
+    if (i < n) a.v.rew[i] = 0.0f;
     if (a.v.done_count && i < 2) a.v.done_count[i] = 0u;
     float o[DRONE_OBS_DIM];
-    lane_obs(sp, L, o);
-    store_obs_wave(a.v.obs, obs_tile[wave], o, wave_base < n ? wave_base : 0u, wave_base < n ? n : 0u, lane);
+    lane_obs(P, L, o);
+    write_outputs(sh, a.v, a.flags_aligned, o, false, false, i, block_base);
 }
 
 // =====================================================================
@@ -360,65 +310,55 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
 // =====================================================================
 template <int TASK>
 __global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
-    __shared__ KParams sp;
-    __shared__ float4 obs_tile[kWavesPerBlock][kWave * kObsVec];
-    stage_params(sp, a.v.kp);
+    __shared__ Shared sh;
+    const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = threadIdx.x / kWave;
-    const uint32_t wave_base = i - lane;
+    const uint32_t block_base = my_chunk() * kBlock;
+    const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
     Lane L;
     load_lane<TASK>(a.v.planes, np, i, L);
-    float4 l0 = a.v.planes[kL0 * np + i];
-    float4 l1 = a.v.planes[kL1 * np + i];
-    const uint32_t env = sp.env_offset + i;
+    float4 l0 = a.v.planes[kL0 * np + i], l1 = a.v.planes[kL1 * np + i];
+    const uint32_t env = P.env_offset + i;
     float rsum = 0.0f;
     bool any_term = false, any_trunc = false, any_target = false;
     for (uint32_t t = 0; t < horizon; t++) {
         float act[4];
-        random_action(sp.key_action, env, a.gstep + t, act);
+        random_action(P.key_action, env, a.gstep + t, act);
         StepOut out;
-        lane_step<TASK>(sp, L, act, env, a.gstep + t, out);
+        lane_step<TASK>(P, L, act, env, a.gstep + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
         any_target |= out.target_changed;
-        if (out.oob || out.trunc) {
-            l0.x += out.perf; l0.y += out.score; l0.z += out.ep_return; l0.w += out.ep_len;
-            l1.x += 1.0f; l1.y += out.oob ? 1.0f : 0.0f;
-        }
+        if (out.oob || out.trunc) fold_log(l0, l1, out);
     }
     if (valid) {
         store_lane<TASK>(a.v.planes, np, i, L, any_target);
-        a.v.rew[i] = rsum;
+        out_store(&a.v.rew[i], rsum);
         if (any_term || any_trunc) {
             a.v.planes[kL0 * np + i] = l0;
             a.v.planes[kL1 * np + i] = l1;
         }
     }
-    const uint64_t m_term = __ballot(valid && any_term);
-    const uint64_t m_trunc = __ballot(valid && any_trunc);
-    store_flags_wave(a.v.term, m_term, any_term, wave_base, i, n, lane, a.flags_aligned & 1u);
-    store_flags_wave(a.v.trunc, m_trunc, any_trunc, wave_base, i, n, lane, a.flags_aligned & 2u);
     float o[DRONE_OBS_DIM];
-    lane_obs(sp, L, o);
-    store_obs_wave(a.v.obs, obs_tile[wave], o, wave_base < n ? wave_base : 0u, wave_base < n ? n : 0u, lane);
+    lane_obs(P, L, o);
+    write_outputs(sh, a.v, a.flags_aligned, o, any_term, any_trunc, i, block_base);
 }
 
 // =====================================================================
 // synthetic random policy into an action buffer (bench / tests)
 // =====================================================================
-__global__ __launch_bounds__(kBlock) void drone_fill_actions_kernel(const uint32_t* __restrict__ kp, float4* __restrict__ actions,
-                                                                    uint32_t n, uint32_t gstep) {
-    __shared__ KParams sp;
-    stage_params(sp, kp);
+__global__ __launch_bounds__(kBlock) void drone_fill_actions_kernel(StepArgs a, float4* __restrict__ actions) {
+#if DRONE_PARAMS_IN_LDS
+    __shared__ Shared sh;
+#endif
+    const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float a[4];
-    random_action(sp.key_action, sp.env_offset + i, gstep, a);
-    actions[i] = make_float4(a[0], a[1], a[2], a[3]);
+    if (i >= a.v.n) return;
+    float act[4];
+    random_action(P.key_action, P.env_offset + i, a.gstep, act);
+    actions[i] = make_float4(act[0], act[1], act[2], act[3]);
 }
 
 // =====================================================================
@@ -459,10 +399,10 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     StepArgs a;
     a.v = v;
     a.gstep = gstep;
-#if DRONE_PARAMS_IN_SGPR
-    a.kp_val = *v.kp_host;
+    a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
+#if !DRONE_PARAMS_IN_LDS
+    a.kp = *v.kp_host;
 #endif
-    a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 3u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 3u) == 0 ? 2u : 0u);
     return a;
 }
 
@@ -471,18 +411,13 @@ inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 }  // namespace
 
 hipError_t launch_reset(const DeviceView& v, hipStream_t s) {
-    // covers the padding lanes too: grid over n_pad
     drone_reset_kernel<<<dim3(v.n_pad / kBlock), dim3(kBlock), 0, s>>>(make_args(v, 0));
     return hipGetLastError();
 }
 
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s) {
     const StepArgs a = make_args(v, gstep);
-    unsigned blocks = grid_for(v.n);
-#if DRONE_PERSISTENT_BLOCKS_PER_CU > 0
-    if (blocks > 256u * DRONE_PERSISTENT_BLOCKS_PER_CU) blocks = 256u * DRONE_PERSISTENT_BLOCKS_PER_CU;
-#endif
-    const dim3 g(blocks), b(kBlock);
+    const dim3 g(grid_for(v.n)), b(kBlock);
     const bool compact = v.done_ids != nullptr;
     if (task == DRONE_TASK_HOVER) {
         if (compact) drone_step_kernel<DRONE_TASK_HOVER, true><<<g, b, 0, s>>>(a);
@@ -503,7 +438,7 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
 }
 
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s) {
-    drone_fill_actions_kernel<<<dim3(grid_for(v.n)), dim3(kBlock), 0, s>>>(v.kp, reinterpret_cast<float4*>(actions), v.n, gstep);
+    drone_fill_actions_kernel<<<dim3(grid_for(v.n)), dim3(kBlock), 0, s>>>(make_args(v, gstep), reinterpret_cast<float4*>(actions));
     return hipGetLastError();
 }
 

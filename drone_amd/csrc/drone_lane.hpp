@@ -40,39 +40,35 @@ struct StepOut {
 
 DRONE_FN float clampc(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// SPEC.md §4. ct[i] = cmd_i * inv_tau; 60 operations (63 with wind).
 template <int TASK>
-DRONE_FN void deriv(const KParams& P, const Dyn& S, const float (&cmd)[4], const float (&wind)[3], Dyn& D) {
+DRONE_FN void deriv(const KParams& P, const Dyn& S, const float (&ct)[4], const float (&wind)[3], Dyn& D) {
     const float w = S.q[0], x = S.q[1], y = S.q[2], z = S.q[3];
     const float ox = S.o[0], oy = S.o[1], oz = S.o[2];
     const float q0 = S.r[0] * S.r[0], q1 = S.r[1] * S.r[1], q2 = S.r[2] * S.r[2], q3 = S.r[3] * S.r[3];
-    const float f0 = P.k_thrust * q0, f1 = P.k_thrust * q1, f2 = P.k_thrust * q2, f3 = P.k_thrust * q3;
-    const float f01 = f0 + f1, f23 = f2 + f3;
-    const float T = f01 + f23;
-    const float tx = P.arm_xy * (f01 - f23);
-    const float ty = P.arm_xy * ((f1 + f2) - (f0 + f3));
-    const float tz = P.k_torque * ((q0 + q2) - (q1 + q3));
-    const float zx = 2.0f * fma_(x, z, w * y);
-    const float zy = 2.0f * fma_(y, z, -(w * x));
-    const float zz = fma_(-2.0f, fma_(x, x, y * y), 1.0f);
-    const float aT = T * P.inv_mass;
+    const float s01 = q0 + q1, s23 = q2 + q3;
+    const float aT2 = P.kT2_m * (s01 + s23);
+    const float zx = fma_(x, z, w * y);
+    const float zy = fma_(y, z, -(w * x));
+    const float zzh = 0.5f - fma_(x, x, y * y);
     if (TASK == DRONE_TASK_WAYPOINT) {
-        D.v[0] = fma_(aT, zx, -(P.drag_m * (S.v[0] - wind[0])));
-        D.v[1] = fma_(aT, zy, -(P.drag_m * (S.v[1] - wind[1])));
-        D.v[2] = fma_(aT, zz, -P.gravity) - P.drag_m * (S.v[2] - wind[2]);
+        D.v[0] = fma_(aT2, zx, -(P.drag_m * (S.v[0] - wind[0])));
+        D.v[1] = fma_(aT2, zy, -(P.drag_m * (S.v[1] - wind[1])));
+        D.v[2] = fma_(-P.drag_m, S.v[2] - wind[2], fma_(aT2, zzh, -P.gravity));
     } else {  // wind == 0 and v - 0 is exact (SPEC.md §4)
-        D.v[0] = fma_(aT, zx, -(P.drag_m * S.v[0]));
-        D.v[1] = fma_(aT, zy, -(P.drag_m * S.v[1]));
-        D.v[2] = fma_(aT, zz, -P.gravity) - P.drag_m * S.v[2];
+        D.v[0] = fma_(aT2, zx, -(P.drag_m * S.v[0]));
+        D.v[1] = fma_(aT2, zy, -(P.drag_m * S.v[1]));
+        D.v[2] = fma_(-P.drag_m, S.v[2], fma_(aT2, zzh, -P.gravity));
     }
-    D.o[0] = P.inv_ixx * ((tx - P.gx * (oy * oz)) - P.k_ang_damp * ox);
-    D.o[1] = P.inv_iyy * ((ty - P.gy * (oz * ox)) - P.k_ang_damp * oy);
-    D.o[2] = P.inv_izz * ((tz - P.gz * (ox * oy)) - P.k_ang_damp * oz);
+    D.o[0] = fma_(P.cx, s01 - s23, fma_(-P.gxi, oy * oz, -(P.kdx * ox)));
+    D.o[1] = fma_(P.cy, (q1 + q2) - (q0 + q3), fma_(-P.gyi, oz * ox, -(P.kdy * oy)));
+    D.o[2] = fma_(P.cz, (q0 + q2) - (q1 + q3), fma_(-P.gzi, ox * oy, -(P.kdz * oz)));
     D.q[0] = -0.5f * fma_(x, ox, fma_(y, oy, z * oz));
     D.q[1] = 0.5f * fma_(w, ox, fma_(y, oz, -(z * oy)));
     D.q[2] = 0.5f * fma_(w, oy, fma_(z, ox, -(x * oz)));
     D.q[3] = 0.5f * fma_(w, oz, fma_(x, oy, -(y * ox)));
 #pragma unroll
-    for (int i = 0; i < 4; i++) D.r[i] = (cmd[i] - S.r[i]) * P.inv_tau;
+    for (int i = 0; i < 4; i++) D.r[i] = fma_(-P.inv_tau, S.r[i], ct[i]);
 #pragma unroll
     for (int i = 0; i < 3; i++) D.p[i] = S.v[i];
 }
@@ -86,19 +82,19 @@ DRONE_FN void deriv(const KParams& P, const Dyn& S, const float (&cmd)[4], const
     _Pragma("unroll") for (int i = 0; i < 4; i++) { BODY(r, i) }
 
 template <int TASK>
-DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3]) {
+DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&ct)[4], const float (&wind)[3]) {
     Dyn k, A, acc;
     const float h = P.h, hh = P.h_half, h6 = P.h_sixth;
-    deriv<TASK>(P, S, cmd, wind, k);
+    deriv<TASK>(P, S, ct, wind, k);
 #define STAGE1(f, i) acc.f[i] = k.f[i]; A.f[i] = fma_(hh, k.f[i], S.f[i]);
     DRONE_FOR_COMPONENTS(STAGE1)
-    deriv<TASK>(P, A, cmd, wind, k);
+    deriv<TASK>(P, A, ct, wind, k);
 #define STAGE2(f, i) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(hh, k.f[i], S.f[i]);
     DRONE_FOR_COMPONENTS(STAGE2)
-    deriv<TASK>(P, A, cmd, wind, k);
+    deriv<TASK>(P, A, ct, wind, k);
 #define STAGE3(f, i) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(h, k.f[i], S.f[i]);
     DRONE_FOR_COMPONENTS(STAGE3)
-    deriv<TASK>(P, A, cmd, wind, k);
+    deriv<TASK>(P, A, ct, wind, k);
 #define STAGE4(f, i) acc.f[i] = acc.f[i] + k.f[i]; S.f[i] = fma_(h6, acc.f[i], S.f[i]);
     DRONE_FOR_COMPONENTS(STAGE4)
 #undef STAGE1
@@ -154,11 +150,11 @@ DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, f
 // SPEC.md §5 steps 1–9 (everything but the observation).
 template <int TASK>
 DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
-    float a[4], cmd[4];
+    float a[4], ct[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         a[i] = clampc(act[i], -1.0f, 1.0f);
-        cmd[i] = P.half_max_rpm * (a[i] + 1.0f);
+        ct[i] = (P.half_max_rpm * (a[i] + 1.0f)) * P.inv_tau;
     }
     float prev_dist = 0.0f;
     if (TASK == DRONE_TASK_WAYPOINT) {
@@ -173,7 +169,7 @@ DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32
         prev_dist = target_dist(L);
     }
 
-    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind);
+    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, ct, L.wind);
 
     {
         float* q = L.s.q;

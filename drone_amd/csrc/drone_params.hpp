@@ -41,12 +41,12 @@ enum Plane : int {
 // workgroup copies it from HBM into LDS once and lanes read it by broadcast
 // ds_read (no bank conflicts: all lanes hit the same address).
 struct KParams {
-    // integrator / dynamics
+    // integrator / dynamics (premultiplied as SPEC.md §1 defines them)
     float h, h_half, h_sixth;
-    float inv_mass, inv_ixx, inv_iyy, inv_izz;
-    float gx, gy, gz;
-    float arm_xy, drag_m, inv_tau;
-    float k_thrust, k_torque, k_ang_damp, gravity;
+    float kT2_m, cx, cy, cz;
+    float gxi, gyi, gzi;
+    float kdx, kdy, kdz;
+    float drag_m, inv_tau, gravity;
     float half_max_rpm, hover_rpm, max_rpm, max_vel, max_omega;
     // observation scales
     float inv_max_vel, inv_max_omega, inv_max_rpm, inv_bound, half_inv_bound;
@@ -59,8 +59,9 @@ struct KParams {
     uint32_t horizon, substeps;
     uint32_t key_reset, key_action, key_wind, key_waypoint;
     uint32_t env_offset;
+    uint32_t pad_;
 };
-static_assert(sizeof(KParams) == 48 * 4, "KParams is staged as 48 words");
+static_assert(sizeof(KParams) == 48 * 4, "KParams is passed / staged as 48 words");
 constexpr int kParamWords = 48;
 
 // ---- SPEC.md §2: counter RNG ----
@@ -88,19 +89,22 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.h = c.dt / (float)c.substeps;
     p.h_half = 0.5f * p.h;
     p.h_sixth = p.h / 6.0f;
-    p.inv_mass = 1.0f / c.mass;
-    p.inv_ixx = 1.0f / c.ixx;
-    p.inv_iyy = 1.0f / c.iyy;
-    p.inv_izz = 1.0f / c.izz;
-    p.gx = c.izz - c.iyy;
-    p.gy = c.ixx - c.izz;
-    p.gz = c.iyy - c.ixx;
-    p.arm_xy = c.arm * 0.70710678f;
-    p.drag_m = c.k_drag * p.inv_mass;
+    const float inv_mass = 1.0f / c.mass;
+    const float inv_ixx = 1.0f / c.ixx, inv_iyy = 1.0f / c.iyy, inv_izz = 1.0f / c.izz;
+    const float arm_xy = c.arm * 0.70710678f;
+    const float arm_k = arm_xy * c.k_thrust;
+    p.kT2_m = (2.0f * c.k_thrust) * inv_mass;
+    p.cx = arm_k * inv_ixx;
+    p.cy = arm_k * inv_iyy;
+    p.cz = c.k_torque * inv_izz;
+    p.gxi = (c.izz - c.iyy) * inv_ixx;
+    p.gyi = (c.ixx - c.izz) * inv_iyy;
+    p.gzi = (c.iyy - c.ixx) * inv_izz;
+    p.kdx = c.k_ang_damp * inv_ixx;
+    p.kdy = c.k_ang_damp * inv_iyy;
+    p.kdz = c.k_ang_damp * inv_izz;
+    p.drag_m = c.k_drag * inv_mass;
     p.inv_tau = 1.0f / c.motor_tau;
-    p.k_thrust = c.k_thrust;
-    p.k_torque = c.k_torque;
-    p.k_ang_damp = c.k_ang_damp;
     p.gravity = c.gravity;
     p.half_max_rpm = 0.5f * c.max_rpm;
     p.hover_rpm = sqrtf((c.mass * c.gravity) / (4.0f * c.k_thrust));
@@ -133,6 +137,7 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.key_wind = stream_key(seed, kWind);
     p.key_waypoint = stream_key(seed, kWaypoint);
     p.env_offset = c.env_offset;
+    p.pad_ = 0;
 }
 
 }  // namespace drone

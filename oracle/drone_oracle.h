@@ -37,9 +37,10 @@
 /* SPEC.md §1: derived parameters, computed once, in float, in this order. */
 typedef struct Params {
     float h, h_half, h_sixth;
-    float inv_mass, inv_ixx, inv_iyy, inv_izz;
-    float gx, gy, gz;
-    float arm_xy, drag_m, inv_tau;
+    float kT2_m, cx, cy, cz;
+    float gxi, gyi, gzi;
+    float kdx, kdy, kdz;
+    float drag_m, inv_tau;
     float half_max_rpm, hover_rpm;
     float inv_max_vel, inv_max_omega, inv_max_rpm;
     float inv_bound, half_inv_bound;
@@ -50,15 +51,23 @@ static inline void params_derive(const DroneConfig* c, Params* p) {
     p->h = c->dt / (float)c->substeps;
     p->h_half = 0.5f * p->h;
     p->h_sixth = p->h / 6.0f;
-    p->inv_mass = 1.0f / c->mass;
-    p->inv_ixx = 1.0f / c->ixx;
-    p->inv_iyy = 1.0f / c->iyy;
-    p->inv_izz = 1.0f / c->izz;
-    p->gx = c->izz - c->iyy;
-    p->gy = c->ixx - c->izz;
-    p->gz = c->iyy - c->ixx;
-    p->arm_xy = c->arm * 0.70710678f;
-    p->drag_m = c->k_drag * p->inv_mass;
+    const float inv_mass = 1.0f / c->mass;
+    const float inv_ixx = 1.0f / c->ixx;
+    const float inv_iyy = 1.0f / c->iyy;
+    const float inv_izz = 1.0f / c->izz;
+    const float arm_xy = c->arm * 0.70710678f;
+    const float arm_k = arm_xy * c->k_thrust;
+    p->kT2_m = (2.0f * c->k_thrust) * inv_mass;
+    p->cx = arm_k * inv_ixx;
+    p->cy = arm_k * inv_iyy;
+    p->cz = c->k_torque * inv_izz;
+    p->gxi = (c->izz - c->iyy) * inv_ixx;
+    p->gyi = (c->ixx - c->izz) * inv_iyy;
+    p->gzi = (c->iyy - c->ixx) * inv_izz;
+    p->kdx = c->k_ang_damp * inv_ixx;
+    p->kdy = c->k_ang_damp * inv_iyy;
+    p->kdz = c->k_ang_damp * inv_izz;
+    p->drag_m = c->k_drag * inv_mass;
     p->inv_tau = 1.0f / c->motor_tau;
     p->half_max_rpm = 0.5f * c->max_rpm;
     p->hover_rpm = sqrtf((c->mass * c->gravity) / (4.0f * c->k_thrust));
@@ -129,64 +138,59 @@ typedef struct Drone {
     const uint32_t* gstep; /* vec-level step counter */
 } Drone;
 
-/* SPEC.md §4: deriv */
-static inline void deriv(const Drone* env, const State* S, const float cmd[4], State* D) {
+/* SPEC.md §4: deriv. ct[i] = cmd_i * inv_tau. */
+static inline void deriv(const Drone* env, const State* S, const float ct[4], State* D) {
     const DroneConfig* c = env->cfg;
     const Params* p = env->par;
     const float w = S->quat[0], x = S->quat[1], y = S->quat[2], z = S->quat[3];
     const float ox = S->omega[0], oy = S->omega[1], oz = S->omega[2];
-    float q[4], f[4];
-    for (int i = 0; i < 4; i++) {
-        q[i] = S->rpm[i] * S->rpm[i];
-        f[i] = c->k_thrust * q[i];
-    }
-    const float T = (f[0] + f[1]) + (f[2] + f[3]);
-    const float tx = p->arm_xy * ((f[0] + f[1]) - (f[2] + f[3]));
-    const float ty = p->arm_xy * ((f[1] + f[2]) - (f[0] + f[3]));
-    const float tz = c->k_torque * ((q[0] + q[2]) - (q[1] + q[3]));
-    const float zx = 2.0f * fmaf(x, z, w * y);
-    const float zy = 2.0f * fmaf(y, z, -(w * x));
-    const float zz = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
-    const float aT = T * p->inv_mass;
-    D->vel[0] = fmaf(aT, zx, -(p->drag_m * (S->vel[0] - env->wind[0])));
-    D->vel[1] = fmaf(aT, zy, -(p->drag_m * (S->vel[1] - env->wind[1])));
-    D->vel[2] = fmaf(aT, zz, -c->gravity) - p->drag_m * (S->vel[2] - env->wind[2]);
-    D->omega[0] = p->inv_ixx * ((tx - p->gx * (oy * oz)) - c->k_ang_damp * ox);
-    D->omega[1] = p->inv_iyy * ((ty - p->gy * (oz * ox)) - c->k_ang_damp * oy);
-    D->omega[2] = p->inv_izz * ((tz - p->gz * (ox * oy)) - c->k_ang_damp * oz);
+    float q[4];
+    for (int i = 0; i < 4; i++) q[i] = S->rpm[i] * S->rpm[i];
+    const float s01 = q[0] + q[1];
+    const float s23 = q[2] + q[3];
+    const float aT2 = p->kT2_m * (s01 + s23);
+    const float zx = fmaf(x, z, w * y);
+    const float zy = fmaf(y, z, -(w * x));
+    const float zzh = 0.5f - fmaf(x, x, y * y);
+    D->vel[0] = fmaf(aT2, zx, -(p->drag_m * (S->vel[0] - env->wind[0])));
+    D->vel[1] = fmaf(aT2, zy, -(p->drag_m * (S->vel[1] - env->wind[1])));
+    D->vel[2] = fmaf(-p->drag_m, S->vel[2] - env->wind[2], fmaf(aT2, zzh, -c->gravity));
+    D->omega[0] = fmaf(p->cx, s01 - s23, fmaf(-p->gxi, oy * oz, -(p->kdx * ox)));
+    D->omega[1] = fmaf(p->cy, (q[1] + q[2]) - (q[0] + q[3]), fmaf(-p->gyi, oz * ox, -(p->kdy * oy)));
+    D->omega[2] = fmaf(p->cz, (q[0] + q[2]) - (q[1] + q[3]), fmaf(-p->gzi, ox * oy, -(p->kdz * oz)));
     D->quat[0] = -0.5f * fmaf(x, ox, fmaf(y, oy, z * oz));
     D->quat[1] = 0.5f * fmaf(w, ox, fmaf(y, oz, -(z * oy)));
     D->quat[2] = 0.5f * fmaf(w, oy, fmaf(z, ox, -(x * oz)));
     D->quat[3] = 0.5f * fmaf(w, oz, fmaf(x, oy, -(y * ox)));
-    for (int i = 0; i < 4; i++) D->rpm[i] = (cmd[i] - S->rpm[i]) * p->inv_tau;
+    for (int i = 0; i < 4; i++) D->rpm[i] = fmaf(-p->inv_tau, S->rpm[i], ct[i]);
     for (int i = 0; i < 3; i++) D->pos[i] = S->vel[i];
 }
 
 #define NCOMP 17 /* State is 17 contiguous floats */
 
-static inline void rk4_substep(Drone* env, const float cmd[4]) {
+static inline void rk4_substep(Drone* env, const float ct[4]) {
     const Params* p = env->par;
     State k, A, acc;
     float* S = (float*)&env->s;
     float* kk = (float*)&k;
     float* AA = (float*)&A;
     float* ac = (float*)&acc;
-    deriv(env, &env->s, cmd, &k);
+    deriv(env, &env->s, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = kk[c];
         AA[c] = fmaf(p->h_half, kk[c], S[c]);
     }
-    deriv(env, &A, cmd, &k);
+    deriv(env, &A, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = fmaf(2.0f, kk[c], ac[c]);
         AA[c] = fmaf(p->h_half, kk[c], S[c]);
     }
-    deriv(env, &A, cmd, &k);
+    deriv(env, &A, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = fmaf(2.0f, kk[c], ac[c]);
         AA[c] = fmaf(p->h, kk[c], S[c]);
     }
-    deriv(env, &A, cmd, &k);
+    deriv(env, &A, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = ac[c] + kk[c];
         S[c] = fmaf(p->h_sixth, ac[c], S[c]);
@@ -282,10 +286,11 @@ static inline void c_step(Drone* env) {
     const DroneConfig* c = env->cfg;
     const Params* p = env->par;
     State* s = &env->s;
-    float a[4], cmd[4];
+    float a[4], ct[4];
     for (int i = 0; i < 4; i++) {
         a[i] = clampc(env->actions[i], -1.0f, 1.0f);
-        cmd[i] = p->half_max_rpm * (a[i] + 1.0f);
+        const float cmd = p->half_max_rpm * (a[i] + 1.0f);
+        ct[i] = cmd * p->inv_tau;
     }
     float prev_dist = 0.0f;
     if (c->task == DRONE_TASK_WAYPOINT) {
@@ -299,7 +304,7 @@ static inline void c_step(Drone* env) {
         prev_dist = target_dist(env);
     }
 
-    for (int k = 0; k < c->substeps; k++) rk4_substep(env, cmd);
+    for (int k = 0; k < c->substeps; k++) rk4_substep(env, ct);
     {
         float* q = s->quat;
         const float n2 = fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3])));

@@ -65,7 +65,7 @@ def test_kparams_match_oracle_params(lane, oracle):
     lane.lane_host_kparams(C.byref(cfg), C.c_uint64(9), p(kp))
     f = kp.view(np.float32)
     # oracle Params order -> KParams word index
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 17, 18, 22, 23, 24, 25, 26, 33, 34]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 21, 22, 23, 24, 25, 32, 33]
     assert_bits_equal(want, f[idx].copy(), "derived params")
     keys = [oracle.lib().oracle_stream_key(9, s) for s in range(4)]
-    assert list(kp[43:47]) == keys
+    assert list(kp[42:46]) == keys

@@ -98,7 +98,7 @@ def main():
         med = statistics.median(ts)
         base = base or med
         print(json.dumps({"variant": name, "spec": specs[name][2], "median_us": round(med, 2), "min_us": round(min(ts), 2),
-                          "max_us": round(max(ts), 2), "vs_first": round(med / base, 4)}))
+                          "max_us": round(max(ts), 2), "vs_first": round(med / base, 4), "all": [round(t, 1) for t in ts]}))
 
 
 if __name__ == "__main__":
