@@ -15,7 +15,7 @@ struct DeviceView {
     uint32_t n;          // envs on this device
     uint32_t n_pad;      // n rounded up to a whole workgroup: lanes [n, n_pad) exist and hold a valid reset state
     uint32_t stride;     // float4 elements between consecutive planes (>= n_pad; padded so planes start on different HBM channels)
-    const uint32_t* kp;  // KParams in HBM (kParamWords words) — staged to LDS per workgroup
+    const uint32_t* kp;  // KParams in HBM (kParamWords words) — read only by the LDS-staging build
     const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)
     float* obs;          // [n][20]
     const float* act;    // [n][4]

@@ -8,7 +8,7 @@
 // (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), no transcendental
 // calls. That is what makes the result bit-identical to the scalar CPU oracle.
 //
-// `P` is a reference to the KParams block; in the kernels it lives in LDS.
+// `P` is a reference to the KParams block (kernarg segment or LDS in the kernels).
 #pragma once
 
 #include "drone_params.hpp"

@@ -1,4 +1,4 @@
-// drone_params.hpp — constants block staged into LDS by every kernel, the
+// drone_params.hpp — the constants block every kernel receives (KParams), the
 // counter RNG, and the plane layout of the device state.
 //
 // Follows SPEC.md §1–§3 (this repo's spec; the reference has no source to
@@ -37,9 +37,10 @@ enum Plane : int {
     kNumPlanes = 9
 };
 
-// Everything a lane needs that is the same for all lanes. 48 words; each
-// workgroup copies it from HBM into LDS once and lanes read it by broadcast
-// ds_read (no bank conflicts: all lanes hit the same address).
+// Everything a lane needs that is the same for all lanes: 48 words. Reaches
+// the lanes through the kernarg segment (scalar loads) or, with
+// -DDRONE_PARAMS_IN_LDS=1, staged HBM -> LDS once per workgroup and read by
+// broadcast ds_read (drone_kernels.hip).
 struct KParams {
     // integrator / dynamics (premultiplied as SPEC.md §1 defines them)
     float h, h_half, h_sixth;

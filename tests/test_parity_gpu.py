@@ -208,3 +208,31 @@ def test_init_failures_are_loud(hip):
         hip.DroneVec(16, cfg=hip.default_config(0, device=63))
     with pytest.raises(RuntimeError):
         hip.DroneVec(0)
+
+
+def test_lds_constants_variant(oracle, hip, tmp_path):
+    """The north-star's "constants staged in LDS" build (-DDRONE_PARAMS_IN_LDS=1)
+    of the same kernels passes the same bit-exact check (the default build passes
+    them through the kernarg segment; DESIGN.md "Constants")."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libdrone_hip_lds.so")
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "drone_amd", "csrc"), "-B", f"OUT={lib}", "EXTRA=-DDRONE_PARAMS_IN_LDS=1"],
+                   check=True, capture_output=True)
+    fns = hip.load_variant(lib)
+    for task in (0, 1):
+        o = oracle.OracleVec(3001, seed=6, cfg=oracle.default_config(task, horizon=90), threads=8)
+        h = hip.DroneVec(3001, seed=6, cfg=hip.default_config(task, horizon=90), fns=fns)
+        o.reset(6)
+        h.reset(6)
+        for t in range(200):
+            o.fill_random_actions()
+            set_actions(h, o.actions)
+            o.step()
+            h.step()
+        o.rollout(50)
+        h.rollout(50)
+        assert_outputs_equal(o, h, "lds variant")
+        assert_state_equal(o.get_state(), h.get_state(), "lds variant state")
