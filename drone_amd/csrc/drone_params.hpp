@@ -37,13 +37,14 @@ enum Plane : int {
     kNumPlanes = 9
 };
 
-// Everything a lane needs that is the same for all lanes: 48 words. Reaches
+// Everything a lane needs that is the same for all lanes: 52 words. Reaches
 // the lanes through the kernarg segment (scalar loads) or, with
 // -DDRONE_PARAMS_IN_LDS=1, staged HBM -> LDS once per workgroup and read by
 // broadcast ds_read (drone_kernels.hip).
 struct KParams {
     // integrator / dynamics (premultiplied as SPEC.md §1 defines them)
     float h, h_half, h_sixth;
+    float hq, hq_half, hq_sixth;  // quaternion rows integrate 2*qdot with halved steps
     float kT2_m, cx, cy, cz;
     float gxi, gyi, gzi;
     float kdx, kdy, kdz;
@@ -60,10 +61,10 @@ struct KParams {
     uint32_t horizon, substeps;
     uint32_t key_reset, key_action, key_wind, key_waypoint;
     uint32_t env_offset;
-    uint32_t pad_;
+    uint32_t pad_[2];
 };
-static_assert(sizeof(KParams) == 48 * 4, "KParams is passed / staged as 48 words");
-constexpr int kParamWords = 48;
+static_assert(sizeof(KParams) == 52 * 4, "KParams is passed / staged as 52 words");
+constexpr int kParamWords = 52;
 
 // ---- SPEC.md §2: counter RNG ----
 DRONE_FN uint32_t hash32(uint32_t x) {
@@ -90,6 +91,9 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.h = c.dt / (float)c.substeps;
     p.h_half = 0.5f * p.h;
     p.h_sixth = p.h / 6.0f;
+    p.hq = 0.5f * p.h;
+    p.hq_half = 0.5f * p.h_half;
+    p.hq_sixth = 0.5f * p.h_sixth;
     const float inv_mass = 1.0f / c.mass;
     const float inv_ixx = 1.0f / c.ixx, inv_iyy = 1.0f / c.iyy, inv_izz = 1.0f / c.izz;
     const float arm_xy = c.arm * 0.70710678f;
@@ -138,7 +142,7 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.key_wind = stream_key(seed, kWind);
     p.key_waypoint = stream_key(seed, kWaypoint);
     p.env_offset = c.env_offset;
-    p.pad_ = 0;
+    p.pad_[0] = p.pad_[1] = 0;
 }
 
 }  // namespace drone

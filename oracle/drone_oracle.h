@@ -37,6 +37,7 @@
 /* SPEC.md §1: derived parameters, computed once, in float, in this order. */
 typedef struct Params {
     float h, h_half, h_sixth;
+    float hq, hq_half, hq_sixth;
     float kT2_m, cx, cy, cz;
     float gxi, gyi, gzi;
     float kdx, kdy, kdz;
@@ -51,6 +52,9 @@ static inline void params_derive(const DroneConfig* c, Params* p) {
     p->h = c->dt / (float)c->substeps;
     p->h_half = 0.5f * p->h;
     p->h_sixth = p->h / 6.0f;
+    p->hq = 0.5f * p->h;
+    p->hq_half = 0.5f * p->h_half;
+    p->hq_sixth = 0.5f * p->h_sixth;
     const float inv_mass = 1.0f / c->mass;
     const float inv_ixx = 1.0f / c->ixx;
     const float inv_iyy = 1.0f / c->iyy;
@@ -99,7 +103,7 @@ static inline uint32_t rng_draw(uint32_t base, uint32_t d) { return hash32(base 
 static inline float u01(uint32_t u) { return (float)(u >> 8) * 5.9604645e-8f; }
 static inline float sym(uint32_t u) { return fmaf(2.0f, u01(u), -1.0f); }
 static inline float s16(uint32_t h) { return (float)((int)h - 32768) * 3.0517578125e-5f; }
-static inline float clampc(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float clampc(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 static inline void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float a[4]) {
     uint32_t b = rng_base(key_action, env, gstep);
@@ -158,15 +162,18 @@ static inline void deriv(const Drone* env, const State* S, const float ct[4], St
     D->omega[0] = fmaf(p->cx, s01 - s23, fmaf(-p->gxi, oy * oz, -(p->kdx * ox)));
     D->omega[1] = fmaf(p->cy, (q[1] + q[2]) - (q[0] + q[3]), fmaf(-p->gyi, oz * ox, -(p->kdy * oy)));
     D->omega[2] = fmaf(p->cz, (q[0] + q[2]) - (q[1] + q[3]), fmaf(-p->gzi, ox * oy, -(p->kdz * oz)));
-    D->quat[0] = -0.5f * fmaf(x, ox, fmaf(y, oy, z * oz));
-    D->quat[1] = 0.5f * fmaf(w, ox, fmaf(y, oz, -(z * oy)));
-    D->quat[2] = 0.5f * fmaf(w, oy, fmaf(z, ox, -(x * oz)));
-    D->quat[3] = 0.5f * fmaf(w, oz, fmaf(x, oy, -(y * ox)));
+    D->quat[0] = -fmaf(x, ox, fmaf(y, oy, z * oz)); /* q (x) (0, omega) = 2 qdot; the 1/2 is in hq* */
+    D->quat[1] = fmaf(w, ox, fmaf(y, oz, -(z * oy)));
+    D->quat[2] = fmaf(w, oy, fmaf(z, ox, -(x * oz)));
+    D->quat[3] = fmaf(w, oz, fmaf(x, oy, -(y * ox)));
     for (int i = 0; i < 4; i++) D->rpm[i] = fmaf(-p->inv_tau, S->rpm[i], ct[i]);
     for (int i = 0; i < 3; i++) D->pos[i] = S->vel[i];
 }
 
 #define NCOMP 17 /* State is 17 contiguous floats */
+
+#define QUAT_FIRST 6 /* components 6..9 of State are the quaternion */
+#define QUAT_LAST 9
 
 static inline void rk4_substep(Drone* env, const float ct[4]) {
     const Params* p = env->par;
@@ -175,25 +182,32 @@ static inline void rk4_substep(Drone* env, const float ct[4]) {
     float* kk = (float*)&k;
     float* AA = (float*)&A;
     float* ac = (float*)&acc;
+    float H[NCOMP], Hh[NCOMP], H6[NCOMP];
+    for (int c = 0; c < NCOMP; c++) {
+        const int is_q = c >= QUAT_FIRST && c <= QUAT_LAST;
+        H[c] = is_q ? p->hq : p->h;
+        Hh[c] = is_q ? p->hq_half : p->h_half;
+        H6[c] = is_q ? p->hq_sixth : p->h_sixth;
+    }
     deriv(env, &env->s, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = kk[c];
-        AA[c] = fmaf(p->h_half, kk[c], S[c]);
+        AA[c] = fmaf(Hh[c], kk[c], S[c]);
     }
     deriv(env, &A, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = fmaf(2.0f, kk[c], ac[c]);
-        AA[c] = fmaf(p->h_half, kk[c], S[c]);
+        AA[c] = fmaf(Hh[c], kk[c], S[c]);
     }
     deriv(env, &A, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = fmaf(2.0f, kk[c], ac[c]);
-        AA[c] = fmaf(p->h, kk[c], S[c]);
+        AA[c] = fmaf(H[c], kk[c], S[c]);
     }
     deriv(env, &A, ct, &k);
     for (int c = 0; c < NCOMP; c++) {
         ac[c] = ac[c] + kk[c];
-        S[c] = fmaf(p->h_sixth, ac[c], S[c]);
+        S[c] = fmaf(H6[c], ac[c], S[c]);
     }
 }
 
@@ -308,11 +322,11 @@ static inline void c_step(Drone* env) {
     {
         float* q = s->quat;
         const float n2 = fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3])));
-        const float inv = 1.0f / sqrtf(n2);
-        for (int i = 0; i < 4; i++) q[i] = q[i] * inv;
+        const float sc = fmaf(-0.5f, n2, 1.5f); /* one Newton step of 1/sqrt(n2) about 1 */
+        for (int i = 0; i < 4; i++) q[i] = q[i] * sc;
         for (int i = 0; i < 3; i++) s->vel[i] = clampc(s->vel[i], -c->max_vel, c->max_vel);
         for (int i = 0; i < 3; i++) s->omega[i] = clampc(s->omega[i], -c->max_omega, c->max_omega);
-        for (int i = 0; i < 4; i++) s->rpm[i] = clampc(s->rpm[i], 0.0f, c->max_rpm);
+        for (int i = 0; i < 4; i++) s->rpm[i] = fminf(s->rpm[i] < 0.0f ? 0.0f : s->rpm[i], c->max_rpm);
     }
     env->tick += 1;
 
@@ -325,7 +339,7 @@ static inline void c_step(Drone* env) {
     const float pen = fmaf(c->c_omega, w2, c->c_action * a2);
     float r;
     if (c->task == DRONE_TASK_HOVER) {
-        r = 1.0f / (1.0f + dist) - pen;
+        r = fmaf(-p->half_inv_bound, dist, 1.0f) - pen;
         if (dist < c->hover_radius) env->score_count += 1;
     } else {
         r = c->progress_scale * (prev_dist - dist) - pen;

@@ -82,9 +82,9 @@ void lane_host_step(const DroneConfig* cfg, uint64_t seed, uint32_t gstep, Drone
     }
 }
 
-void lane_host_kparams(const DroneConfig* cfg, uint64_t seed, uint32_t* out48) {
+void lane_host_kparams(const DroneConfig* cfg, uint64_t seed, uint32_t* out52) {
     KParams P;
     derive_kparams(*cfg, seed, P);
-    memcpy(out48, &P, sizeof(P));
+    memcpy(out52, &P, sizeof(P));
 }
 }

@@ -68,7 +68,7 @@ def hover_reward(c, S, target, actions):
     p, v, q, o, r = S
     a = np.clip(actions, -1, 1)
     dist = np.linalg.norm(target - p, axis=1)
-    return 1 / (1 + dist) - (c["c_omega"] * (o * o).sum(1) + c["c_action"] * (a * a).sum(1))
+    return 1 - dist * (0.5 / c["bound"]) - (c["c_omega"] * (o * o).sum(1) + c["c_action"] * (a * a).sum(1))
 
 
 def obs(c, S, target):

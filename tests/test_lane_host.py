@@ -61,11 +61,11 @@ def test_lane_math_bit_exact_vs_oracle(lane, oracle, task, horizon, substeps):
 def test_kparams_match_oracle_params(lane, oracle):
     cfg = oracle.default_config(1, substeps=3, dt=0.02)
     want = oracle.params(cfg)
-    kp = np.zeros(48, np.uint32)
+    kp = np.zeros(52, np.uint32)
     lane.lane_host_kparams(C.byref(cfg), C.c_uint64(9), p(kp))
     f = kp.view(np.float32)
     # oracle Params order -> KParams word index
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 21, 22, 23, 24, 25, 32, 33]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27, 28, 35, 36]
     assert_bits_equal(want, f[idx].copy(), "derived params")
     keys = [oracle.lib().oracle_stream_key(9, s) for s in range(4)]
-    assert list(kp[42:46]) == keys
+    assert list(kp[45:49]) == keys
