@@ -43,6 +43,13 @@
 #define DRONE_STEP_MAX_WAVES 0
 #endif
 
+#ifndef DRONE_ROLLOUT_MIN_WAVES  // __launch_bounds__ 2nd argument of the fused rollout kernel; 0 = unset
+#define DRONE_ROLLOUT_MIN_WAVES 0
+#endif
+#ifndef DRONE_ROLLOUT_MAX_WAVES  // >0: cap waves per SIMD of the fused rollout kernel
+#define DRONE_ROLLOUT_MAX_WAVES 0
+#endif
+
 namespace drone {
 
 namespace {
@@ -308,8 +315,19 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
 // whole horizon; actions come from the counter RNG; HBM is touched once on
 // the way in and once on the way out.
 // =====================================================================
+#if DRONE_ROLLOUT_MIN_WAVES > 0
+#define DRONE_ROLLOUT_BOUNDS __launch_bounds__(kBlock, DRONE_ROLLOUT_MIN_WAVES)
+#else
+#define DRONE_ROLLOUT_BOUNDS __launch_bounds__(kBlock)
+#endif
+#if DRONE_ROLLOUT_MAX_WAVES > 0
+#define DRONE_ROLLOUT_WAVES __attribute__((amdgpu_waves_per_eu(1, DRONE_ROLLOUT_MAX_WAVES)))
+#else
+#define DRONE_ROLLOUT_WAVES
+#endif
+
 template <int TASK>
-__global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
+__global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
