@@ -37,7 +37,13 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def hip():
+    """The product binding. The shared object is git-ignored, so a fresh checkout
+    has to compile it first (hipcc cross-compiles gfx950 without a GPU)."""
+    import subprocess
+
     from drone_amd import binding
 
+    if not os.path.exists(binding.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "drone_amd", "csrc")], check=True, capture_output=True)
     binding.load()
     return binding
