@@ -69,3 +69,46 @@ def test_kparams_match_oracle_params(lane, oracle):
     assert_bits_equal(want, f[idx].copy(), "derived params")
     keys = [oracle.lib().oracle_stream_key(9, s) for s in range(4)]
     assert list(kp[45:49]) == keys
+
+
+def test_random_configs_bit_exact(lane, oracle):
+    """Twenty random (but physical) configurations — masses, inertias, step sizes,
+    substeps, bounds, wind and reward weights — lane math vs oracle, bit for bit."""
+    rng = np.random.default_rng(123)
+    n = 256
+    for trial in range(20):
+        task = trial % 2
+        over = dict(
+            horizon=int(rng.integers(5, 120)), substeps=int(rng.integers(1, 4)), dt=float(rng.uniform(0.002, 0.03)),
+            mass=float(rng.uniform(0.02, 1.5)), arm=float(rng.uniform(0.03, 0.3)),
+            ixx=float(rng.uniform(1e-5, 1e-2)), iyy=float(rng.uniform(1e-5, 1e-2)), izz=float(rng.uniform(2e-5, 2e-2)),
+            k_thrust=float(rng.uniform(1e-10, 1e-7)), k_torque=float(rng.uniform(1e-12, 1e-9)),
+            k_drag=float(rng.uniform(0, 0.05)), k_ang_damp=float(rng.uniform(0, 1e-4)), gravity=float(rng.uniform(1.6, 12)),
+            max_rpm=float(rng.uniform(5000, 30000)), motor_tau=float(rng.uniform(0.01, 0.2)),
+            max_vel=float(rng.uniform(5, 40)), max_omega=float(rng.uniform(10, 80)), bound=float(rng.uniform(2, 20)),
+            spawn_extent=float(rng.uniform(0.5, 2)), target_extent=float(rng.uniform(0.5, 2)), tilt_init=float(rng.uniform(0, 0.5)),
+            hover_radius=float(rng.uniform(0.1, 2)), waypoint_radius=float(rng.uniform(0.1, 3)),
+            wind_theta=float(rng.uniform(0, 2)), wind_sigma=float(rng.uniform(0, 3)), wind_max=float(rng.uniform(1, 8)),
+            c_omega=float(rng.uniform(0, 1e-3)), c_action=float(rng.uniform(0, 0.1)), crash_penalty=float(rng.uniform(0, 5)),
+            progress_scale=float(rng.uniform(0.1, 3)), waypoint_bonus=float(rng.uniform(0, 3)),
+            env_offset=int(rng.integers(0, 2**31)))
+        seed = int(rng.integers(0, 2**63))
+        cfg = oracle.default_config(task, **over)
+        v = oracle.OracleVec(n, seed=seed, cfg=cfg)
+        v.reset(seed)
+        rows = np.zeros(n, dtype=abi.state_row_dtype())
+        obs = np.zeros((n, 20), np.float32)
+        act = np.zeros((n, 4), np.float32)
+        rew = np.zeros(n, np.float32)
+        term = np.zeros(n, np.uint8)
+        trunc = np.zeros(n, np.uint8)
+        lane.lane_host_reset(C.byref(cfg), C.c_uint64(seed), p(rows), p(obs), n)
+        assert_state_equal(v.get_state(), rows, f"trial {trial} reset")
+        for t in range(150):
+            v.fill_random_actions()
+            g = v.gstep
+            v.step()
+            lane.lane_host_step(C.byref(cfg), C.c_uint64(seed), C.c_uint32(g), p(rows), p(act), p(obs), p(rew), p(term), p(trunc), n, 1)
+            assert_bits_equal(v.observations, obs, f"trial {trial} obs {t}")
+            assert_bits_equal(v.rewards, rew, f"trial {trial} rew {t}")
+        assert_state_equal(v.get_state(), rows, f"trial {trial} final")

@@ -236,3 +236,59 @@ def test_lds_constants_variant(oracle, hip, tmp_path):
         h.rollout(50)
         assert_outputs_equal(o, h, "lds variant")
         assert_state_equal(o.get_state(), h.get_state(), "lds variant state")
+
+
+def test_non_default_physics_config(oracle, hip):
+    """A heavier airframe, 3 RK4 substeps, other step size, bounds and reward weights."""
+    over = dict(horizon=77, substeps=3, dt=0.02, mass=0.8, arm=0.18, ixx=4.0e-3, iyy=5.0e-3, izz=8.0e-3, k_thrust=2.0e-8,
+                k_torque=3.0e-10, k_drag=0.03, k_ang_damp=2.0e-5, gravity=3.7, max_rpm=12000.0, motor_tau=0.08, max_vel=12.0,
+                max_omega=25.0, bound=8.0, spawn_extent=1.5, target_extent=2.5, tilt_init=0.3, waypoint_radius=1.5,
+                wind_theta=1.0, wind_sigma=2.0, wind_max=4.0, c_omega=3e-4, c_action=0.05, crash_penalty=2.0,
+                progress_scale=2.0, waypoint_bonus=0.5, env_offset=4000000000)
+    for task in (0, 1):
+        o, h = make_pair(oracle, hip, 2049, 5150, task, **over)
+        for t in range(300):
+            o.fill_random_actions()
+            set_actions(h, o.actions)
+            o.step()
+            h.step()
+        assert_outputs_equal(o, h, "non-default cfg")
+        assert_state_equal(o.get_state(), h.get_state(), "non-default cfg state")
+        assert o.get_state()["episode"].sum() > 0
+
+
+def test_unaligned_flag_buffers_take_the_byte_path(oracle, hip):
+    """terminals / truncations handed over at odd addresses: the kernels fall back
+    from 16-B packed flag stores to per-lane byte stores; results are the same."""
+    import ctypes as C
+
+    import torch
+
+    n, seed = 1000, 13
+    cfg = hip.default_config(0, horizon=30, buffer_kind=abi.BUFFERS_DEVICE, device=0)
+    dev = torch.device("cuda:0")
+    obs = torch.zeros((n, abi.OBS_DIM), dtype=torch.float32, device=dev)
+    act = torch.zeros((n, abi.ACT_DIM), dtype=torch.float32, device=dev)
+    rew = torch.zeros(n, dtype=torch.float32, device=dev)
+    flags = torch.full((2, n + 64), 7, dtype=torch.uint8, device=dev)
+    term, trunc = flags[0, 1:n + 1], flags[1, 3:n + 3]
+    assert term.data_ptr() % 2 == 1 and trunc.data_ptr() % 2 == 1
+    f = hip.load_variant(hip.LIB_PATH)
+    h = f["drone_vec_init"](obs.data_ptr(), act.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(), n, seed, C.byref(cfg))
+    assert h, f["drone_last_error"]()
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(0, horizon=30))
+    f["drone_vec_reset"](h, seed)
+    o.reset(seed)
+    for t in range(70):
+        o.fill_random_actions()
+        act.copy_(torch.from_numpy(o.actions))
+        o.step()
+        f["drone_vec_step"](h)
+        f["drone_vec_sync"](h)
+        assert_bits_equal(o.terminals, term, f"unaligned terminals {t}")
+        assert_bits_equal(o.truncations, trunc, f"unaligned truncations {t}")
+    assert_bits_equal(o.observations, obs, "obs")
+    # guard bytes around the slices untouched
+    fl = flags.cpu().numpy()
+    assert fl[0, 0] == 7 and fl[0, n + 1] == 7 and fl[1, 2] == 7 and fl[1, n + 3] == 7
+    f["drone_vec_close"](h)
