@@ -84,6 +84,7 @@ SYMBOLS = {
     "drone_vec_set_stream": (C.c_int, [_P, _P]),
     "drone_vec_sync": (C.c_int, [_P]),
     "drone_vec_bind_actions": (C.c_int, [_P, _P]),
+    "drone_vec_bind_outputs": (C.c_int, [_P, _P, _P, _P, _P]),
     "drone_vec_fill_random_actions": (C.c_int, [_P, _P, C.c_uint32]),
     "drone_vec_gstep": (C.c_uint32, [_P]),
     "drone_vec_num_envs": (C.c_int, [_P]),

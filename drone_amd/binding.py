@@ -169,6 +169,10 @@ class DroneVec:
         self._check(self._f["drone_vec_bind_actions"](self._h, _ptr(actions)))
         self.actions = actions
 
+    def bind_outputs(self, observations, rewards, terminals, truncations):
+        self._check(self._f["drone_vec_bind_outputs"](self._h, _ptr(observations), _ptr(rewards), _ptr(terminals), _ptr(truncations)))
+        self.observations, self.rewards, self.terminals, self.truncations = observations, rewards, terminals, truncations
+
     def fill_random_actions(self, gstep=None, out=None):
         out = self.actions if out is None else out
         g = self.gstep if gstep is None else gstep

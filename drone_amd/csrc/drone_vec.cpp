@@ -64,6 +64,7 @@ struct DroneVec {
     unsigned char* u_term;
     unsigned char* u_trunc;
     bool registered[5];
+    void* registered_ptr[5];
     // device side
     DeviceView dv;
     uint32_t* d_kp;
@@ -138,6 +139,7 @@ void try_register(DroneVec* v, int slot, void* p, size_t bytes) {
     // Pin the caller's pages so the per-step copies are true async DMA. Not
     // fatal if it fails (already pinned, or not page-lockable): pageable copies still work.
     v->registered[slot] = (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess);
+    v->registered_ptr[slot] = p;
     if (!v->registered[slot]) (void)hipGetLastError();
 }
 
@@ -307,9 +309,8 @@ void drone_vec_close(DroneVec* v) {
     if (!v) return;
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
-    void* regs[5] = {v->u_obs, v->u_act, v->u_rew, v->u_term, v->u_trunc};
     for (int i = 0; i < 5; i++)
-        if (v->registered[i]) (void)hipHostUnregister(regs[i]);
+        if (v->registered[i]) (void)hipHostUnregister(v->registered_ptr[i]);
     (void)hipFree(v->dv.planes);
     (void)hipFree(v->d_kp);
     (void)hipFree(v->d_partials);
@@ -352,6 +353,21 @@ int drone_vec_bind_actions(DroneVec* v, float* actions) {
         v->u_act = actions;
         v->dv.act = actions;
     }
+    return 0;
+}
+
+int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, unsigned char* terminals, unsigned char* truncations) {
+    if (!v || !observations || !rewards || !terminals || !truncations) { set_err("bind_outputs: NULL argument"); return -1; }
+    if (!v->host_buffers) {
+        if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
+            set_err("device buffers must be 16-byte aligned (observations) and 4-byte aligned (rewards)");
+            return -1;
+        }
+        v->dv.obs = observations; v->dv.rew = rewards; v->dv.term = terminals; v->dv.trunc = truncations;
+    }
+    // host mode: the device mirrors stay; the next step copies out to the new addresses
+    // (pageable unless the caller pinned them)
+    v->u_obs = observations; v->u_rew = rewards; v->u_term = terminals; v->u_trunc = truncations;
     return 0;
 }
 

@@ -67,3 +67,50 @@ class BoundaryGather:
             dist.all_gather_into_tensor(dsts[k], self._pad[k], group=self.group)
         keep = torch.cat([torch.arange(r * self.max_count, r * self.max_count + c, device=self.obs.device) for r, c in enumerate(self.counts)])
         return self.obs[keep], self.rew[keep], self.term[keep], self.trunc[keep]
+
+
+class PipelinedGather:
+    """Overlap the host-boundary all-gather of step k with the kernel of step k+1.
+
+    The env alternates between two output sets (``bind_outputs``): while the
+    collective reads set A on a side stream, the next step writes set B on the
+    main stream. ``step()`` returns the gathered tensors of the step it just
+    launched plus the event that marks them complete; the consumer waits on that
+    event (``torch.cuda.current_stream().wait_event(ev)``) before reading.
+    On CPU tensors (gloo) the same code runs synchronously.
+    """
+
+    def __init__(self, vec, total_envs, obs_dim, group=None):
+        self.vec = vec
+        first = (vec.observations, vec.rewards, vec.terminals, vec.truncations)
+        second = tuple(torch.empty_like(t) for t in first)
+        self.sets = [first, second]
+        dev = first[0].device
+        self.cuda = dev.type == "cuda"
+        self.gathers = [BoundaryGather(total_envs, obs_dim, dev, group), BoundaryGather(total_envs, obs_dim, dev, group)]
+        self.k = 0
+        if self.cuda:
+            self.comm = torch.cuda.Stream(device=dev)
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+            for ev in self.done:
+                ev.record(torch.cuda.current_stream(dev))
+
+    def step(self):
+        i = self.k & 1
+        self.k += 1
+        outs = self.sets[i]
+        if not self.cuda:
+            self.vec.bind_outputs(*outs)
+            self.vec.step()
+            return self.gathers[i](*outs), None
+        main = torch.cuda.current_stream(outs[0].device)
+        main.wait_event(self.done[i])  # the gather that last read this set (two steps ago) has finished
+        self.vec.bind_outputs(*outs)
+        self.vec.step()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ready)
+            gathered = self.gathers[i](*outs)
+            self.done[i].record(self.comm)
+        return gathered, self.done[i]

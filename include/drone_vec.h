@@ -115,6 +115,12 @@ int drone_vec_sync(DroneVec* v);
  * through pre-filled action buffers without copies. */
 int drone_vec_bind_actions(DroneVec* v, float* actions);
 
+/* Rebind the four output buffers (same kind as at init). A consumer that
+ * overlaps a collective or a copy of step k's outputs with step k+1 alternates
+ * between two sets (drone_amd/dist.py PipelinedGather). */
+int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards,
+                           unsigned char* terminals, unsigned char* truncations);
+
 /* Write the SPEC.md §2 random-policy actions for step `gstep` into `actions`
  * (same kind as the handle's buffers). */
 int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep);

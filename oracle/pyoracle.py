@@ -59,7 +59,7 @@ def lib():
         build()
         _lib = C.CDLL(_SO)
         names = [n for n in abi.SYMBOLS if n not in (
-            "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_done_list",
+            "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_bind_outputs", "drone_vec_done_list",
             "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error")]
         _fns = abi.bind(_lib, prefix_to="oracle_", names=names)
         _lib.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]

@@ -38,6 +38,74 @@ def _worker(rank, world, port, total, steps, task, q):
     dist.destroy_process_group()
 
 
+class _OracleAsVec:
+    """Gives the CPU oracle the bind_outputs()/step() surface PipelinedGather drives."""
+
+    def __init__(self, o):
+        self.o = o
+        self.observations = torch.from_numpy(o.observations)
+        self.rewards = torch.from_numpy(o.rewards)
+        self.terminals = torch.from_numpy(o.terminals)
+        self.truncations = torch.from_numpy(o.truncations)
+        self._bound = None
+
+    def bind_outputs(self, obs, rew, term, trunc):
+        self._bound = (obs, rew, term, trunc)
+
+    def step(self):
+        self.o.fill_random_actions()
+        self.o.step()
+        if self._bound is not None:
+            for dst, src in zip(self._bound, (self.o.observations, self.o.rewards, self.o.terminals, self.o.truncations)):
+                dst.copy_(torch.from_numpy(src))
+
+
+def _pipelined_worker(rank, world, port, total, steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drone_amd import abi
+    from drone_amd.dist import PipelinedGather, shard_range
+    from oracle import pyoracle
+
+    off, cnt = shard_range(total, rank, world)
+    o = pyoracle.OracleVec(cnt, seed=9, cfg=pyoracle.default_config(0, env_offset=off, horizon=25))
+    o.reset(9)
+    pg = PipelinedGather(_OracleAsVec(o), total, abi.OBS_DIM)
+    trace = []
+    for _ in range(steps):
+        (obs, rew, term, trunc), ev = pg.step()
+        assert ev is None
+        trace.append((obs.numpy().copy(), rew.numpy().copy(), term.numpy().copy()))
+    if rank == 0:
+        q.put(trace)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_alternates_output_sets(oracle):
+    total, steps, world = 192, 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29400 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    trace = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    whole = oracle.OracleVec(total, seed=9, cfg=oracle.default_config(0, horizon=25))
+    whole.reset(9)
+    for t in range(steps):
+        whole.fill_random_actions()
+        whole.step()
+        obs, rew, term = trace[t]
+        assert obs.tobytes() == whole.observations.tobytes(), t
+        assert rew.tobytes() == whole.rewards.tobytes() and term.tobytes() == whole.terminals.tobytes(), t
+
+
 @pytest.mark.parametrize("total", [256, 257])
 def test_two_rank_shards_equal_single_vec(oracle, total):
     steps, task, world = 50, 1, 2

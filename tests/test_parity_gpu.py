@@ -292,3 +292,41 @@ def test_unaligned_flag_buffers_take_the_byte_path(oracle, hip):
     fl = flags.cpu().numpy()
     assert fl[0, 0] == 7 and fl[0, n + 1] == 7 and fl[1, 2] == 7 and fl[1, n + 3] == 7
     f["drone_vec_close"](h)
+
+
+def test_pipelined_gather_on_gpu(oracle, hip):
+    """bind_outputs + PipelinedGather on the device (RCCL group of one rank): the
+    gathered tensors of step k equal the oracle's outputs of step k while step k+1
+    is already writing the other output set."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from drone_amd.dist import PipelinedGather
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        n, seed = 40000, 77
+        o, h = make_pair(oracle, hip, n, seed, 1, device="cuda:0", horizon=60)
+        pg = PipelinedGather(h, n, abi.OBS_DIM)
+        pending = []
+        for t in range(12):
+            o.fill_random_actions()
+            h.fill_random_actions()
+            (obs, rew, term, trunc), ev = pg.step()
+            o.step()
+            pending.append((obs, rew, term, trunc, ev, o.observations.copy(), o.rewards.copy(), o.terminals.copy(), o.truncations.copy()))
+            if len(pending) == 2:  # consume one step behind, as an overlapped consumer would
+                obs_, rew_, term_, trunc_, ev_, eo, er, et, eu = pending.pop(0)
+                torch.cuda.current_stream().wait_event(ev_)
+                assert_bits_equal(eo, obs_, f"gathered obs {t}")
+                assert_bits_equal(er, rew_, f"gathered rew {t}")
+                assert_bits_equal(et, term_, f"gathered term {t}")
+                assert_bits_equal(eu, trunc_, f"gathered trunc {t}")
+        torch.cuda.synchronize()
+        assert_state_equal(o.get_state(), h.get_state(), "state after pipelined steps")
+    finally:
+        dist.destroy_process_group()
