@@ -12,7 +12,7 @@
 //     lanes — partial-line dword stores of the same bytes cost 11 % of the kernel;
 //   * the optional done-id list is compacted with ballot + mbcnt + one atomic
 //     per wave.
-// The 48-word constants block (KParams) reaches the lanes either through the
+// The 52-word constants block (KParams) reaches the lanes either through the
 // kernarg segment (scalar loads -> SGPR operands; default, measured faster) or
 // staged through LDS by each workgroup (DRONE_PARAMS_IN_LDS=1).
 //
