@@ -138,6 +138,11 @@ def test_edge_states_nan_and_bounds(oracle, hip):
     rows["rpm"][7] = (-5, 1e9, 0, 21702)
     rows["pos"][8] = (0, 0, -b)
     rows["vel"][8] = (0, 0, -20)
+    # subnormal operands: both sides must keep them (gfx950 float_denorm_mode_32 = 3, x86 without FTZ/DAZ)
+    rows["vel"][9] = (1e-40, -1e-41, 3e-39)
+    rows["omega"][9] = (2e-39, -1e-45, 1e-38)
+    rows["omega"][12] = (1e-20, 1e-20, -1e-20)   # products underflow into the subnormal range
+    rows["rpm"][13] = (1e-20, 1e-19, 0.0, 1e-30)
     o.set_state(rows)
     h.set_state(rows)
     assert_state_equal(o.get_state(), h.get_state(), "after set_state")
