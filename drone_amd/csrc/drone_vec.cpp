@@ -57,6 +57,7 @@ struct DroneVec {
     uint32_t stride;
     int device;
     bool host_buffers;
+    bool zero_copy;      // host buffers mapped into the device address space: kernels read / write them over PCIe directly
     // caller buffers (host or device, per cfg.buffer_kind)
     float* u_obs;
     float* u_act;
@@ -75,6 +76,11 @@ struct DroneVec {
     float* d_rew;
     unsigned char* d_term;
     unsigned char* d_trunc;
+    float* m_obs;        // device-visible addresses of the caller's registered host buffers (zero_copy)
+    float* m_act;
+    float* m_rew;
+    unsigned char* m_term;
+    unsigned char* m_trunc;
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
@@ -111,11 +117,16 @@ bool validate(const DroneConfig* c, int num_envs) {
 }
 
 bool host_to_device_actions(DroneVec* v) {
+    if (v->zero_copy) return true;  // the kernel reads the caller's action buffer itself
     HIP_TRY(hipMemcpyAsync(v->d_act, v->u_act, (size_t)v->n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return false);
     return true;
 }
 
 bool device_to_host_outputs(DroneVec* v) {
+    if (v->zero_copy) {  // outputs already landed in the caller's memory: just wait for the kernel
+        HIP_TRY(hipStreamSynchronize(v->stream), return false);
+        return true;
+    }
     const size_t n = (size_t)v->n;
     HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * DRONE_OBS_DIM * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipMemcpyAsync(v->u_rew, v->d_rew, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
@@ -133,6 +144,38 @@ uint32_t plane_pad_elems() {
     const char* e = getenv("DRONE_PLANE_PAD");
     if (e && *e) return (uint32_t)strtoul(e, nullptr, 10);
     return 0;
+}
+
+// Host-buffer mode has two transports. Mirror: actions H2D, kernel on device
+// mirrors, four D2H copies. Zero-copy: the caller's (registered) buffers are
+// mapped into the device address space and the kernel loads the actions and
+// stores its outputs through PCIe itself — no copy commands at all, which is
+// what small vec-envs (launch/copy-latency bound) want. Chosen at init:
+// zero-copy when every buffer could be registered, mapped and is 16-B aligned
+// and the shard is at most DRONE_ZERO_COPY_MAX_ENVS envs (default from
+// measurement); the environment variable DRONE_HOST_ZEROCOPY=0/1 forces it.
+constexpr int kZeroCopyMaxEnvsDefault = 1 << 30;
+
+bool want_zero_copy(int num_envs) {
+    const char* e = getenv("DRONE_HOST_ZEROCOPY");
+    if (e && *e) return atoi(e) != 0;
+    const char* m = getenv("DRONE_ZERO_COPY_MAX_ENVS");
+    const long cap = (m && *m) ? atol(m) : (long)kZeroCopyMaxEnvsDefault;
+    return num_envs <= cap;
+}
+
+void* mapped_ptr(void* host) {
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return d;
+}
+
+void leave_zero_copy(DroneVec* v) {
+    v->zero_copy = false;
+    v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
 }
 
 void try_register(DroneVec* v, int slot, void* p, size_t bytes) {
@@ -241,6 +284,22 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         try_register(v, 3, terminals, n);
         try_register(v, 4, truncations, n);
         v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
+        bool all_reg = true;
+        for (int i = 0; i < 5; i++) all_reg = all_reg && v->registered[i];
+        if (all_reg && want_zero_copy(num_envs)) {
+            v->m_obs = (float*)mapped_ptr(observations);
+            v->m_act = (float*)mapped_ptr(actions);
+            v->m_rew = (float*)mapped_ptr(rewards);
+            v->m_term = (unsigned char*)mapped_ptr(terminals);
+            v->m_trunc = (unsigned char*)mapped_ptr(truncations);
+            const bool ok = v->m_obs && v->m_act && v->m_rew && v->m_term && v->m_trunc &&
+                            !(reinterpret_cast<uintptr_t>(v->m_obs) & 15u) && !(reinterpret_cast<uintptr_t>(v->m_act) & 15u) &&
+                            !(reinterpret_cast<uintptr_t>(v->m_rew) & 3u);
+            if (ok) {
+                v->zero_copy = true;
+                v->dv.obs = v->m_obs; v->dv.act = v->m_act; v->dv.rew = v->m_rew; v->dv.term = v->m_term; v->dv.trunc = v->m_trunc;
+            }
+        }
     } else {
         if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
             set_err("device buffers must be 16-byte aligned (observations, actions) and 4-byte aligned (rewards)");
@@ -347,6 +406,7 @@ int drone_vec_sync(DroneVec* v) {
 int drone_vec_bind_actions(DroneVec* v, float* actions) {
     if (!v || !actions) return -1;
     if (v->host_buffers) {
+        if (v->zero_copy && actions != v->u_act) leave_zero_copy(v);  // an unregistered buffer: back to the mirror transport
         v->u_act = actions;  // copied (pageable unless the caller pinned it) at the next step
     } else {
         if (reinterpret_cast<uintptr_t>(actions) & 15u) { set_err("actions must be 16-byte aligned"); return -1; }
@@ -367,6 +427,8 @@ int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, uns
     }
     // host mode: the device mirrors stay; the next step copies out to the new addresses
     // (pageable unless the caller pinned them)
+    if (v->host_buffers && v->zero_copy && (observations != v->u_obs || rewards != v->u_rew || terminals != v->u_term || truncations != v->u_trunc))
+        leave_zero_copy(v);
     v->u_obs = observations; v->u_rew = rewards; v->u_term = terminals; v->u_trunc = truncations;
     return 0;
 }

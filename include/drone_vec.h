@@ -35,7 +35,7 @@ extern "C" {
 #define DRONE_TASK_HOVER 0
 #define DRONE_TASK_WAYPOINT 1 /* waypoint tracking with OU wind gusts */
 
-#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory: step = H2D, kernel, D2H, sync */
+#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory: registered + mapped, the kernel accesses them over PCIe (fallback: H2D, kernel, D2H); step ends with a sync */
 #define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
 
 /* Env kwargs. Fill with drone_config_default() first, then override. */
