@@ -335,3 +335,32 @@ def test_pipelined_gather_on_gpu(oracle, hip):
         assert_state_equal(o.get_state(), h.get_state(), "state after pipelined steps")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("zero_copy", ["0", "1"])
+def test_host_buffer_transports(oracle, hip, zero_copy, monkeypatch):
+    """Host-buffer mode, both transports: mirror copies (DRONE_HOST_ZEROCOPY=0) and
+    the kernel accessing the caller's registered numpy buffers over PCIe (=1)."""
+    monkeypatch.setenv("DRONE_HOST_ZEROCOPY", zero_copy)
+    o, h = make_pair(oracle, hip, 5000, 41, 1, horizon=50)
+    for t in range(150):
+        o.fill_random_actions()
+        h.actions[:] = o.actions
+        o.step()
+        h.step()
+        assert_outputs_equal(o, h, f"host transport {zero_copy} step {t}")
+    o.rollout(40)
+    h.rollout(40)
+    assert_outputs_equal(o, h, "host transport rollout")
+    # rebinding to fresh (unregistered) numpy buffers must keep working (falls back to the mirror transport)
+    new_act = np.zeros_like(h.actions)
+    new_out = (np.zeros_like(h.observations), np.zeros_like(h.rewards), np.zeros_like(h.terminals), np.zeros_like(h.truncations))
+    h.bind_actions(new_act)
+    h.bind_outputs(*new_out)
+    for t in range(5):
+        o.fill_random_actions()
+        new_act[:] = o.actions
+        o.step()
+        h.step()
+    assert_outputs_equal(o, h, "after rebinding")
+    assert_state_equal(o.get_state(), h.get_state(), "host transport state")
