@@ -52,14 +52,46 @@ def main():
                 continue
         specs[name] = (binding.load_variant(lib), dict(kv.split("=", 1) for kv in filter(None, envs.split(","))), rest)
 
+    import ctypes as C
+
+    hiprt = C.CDLL("libamdhip64.so")
+    hiprt.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hiprt.hipFree.argtypes = [C.c_void_p]
+    FLAGS = {"finegrained": 0x1, "uncached": 0x3, "contiguous": 0x4}
+
+    class RawTensor:
+        """torch view of memory from hipExtMallocWithFlags (experiment: OUT_ALLOC / ACT_ALLOC = uncached | finegrained)."""
+
+        def __init__(self, like, kind):
+            self.ptr = C.c_void_p()
+            nbytes = like.numel() * like.element_size()
+            rc = hiprt.hipExtMallocWithFlags(C.byref(self.ptr), nbytes, FLAGS[kind])
+            assert rc == 0, f"hipExtMallocWithFlags({kind}) -> {rc}"
+            typestr = {torch.float32: "<f4", torch.uint8: "|u1"}[like.dtype]
+            self.__cuda_array_interface__ = {"shape": tuple(like.shape), "typestr": typestr, "data": (self.ptr.value, False), "version": 2}
+            self.tensor = torch.as_tensor(self, device=like.device)
+
+        def free(self):
+            hiprt.hipFree(self.ptr)
+
     def make(name):
         fns, envs, _ = specs[name]
         os.environ.update(envs)
         v = binding.DroneVec(a.envs, seed=0, task=task, device="cuda:0", fns=fns)
         for k in envs:
             os.environ.pop(k, None)
+        v._raw = []
+        if envs.get("OUT_ALLOC"):
+            outs = [RawTensor(t, envs["OUT_ALLOC"]) for t in (v.observations, v.rewards, v.terminals, v.truncations)]
+            v._raw += outs
+            v.bind_outputs(*[r.tensor for r in outs])
         v.reset(0)
-        ring = [torch.empty_like(v.actions) for _ in range(int(envs.get('RING', a.ring)))]
+        if envs.get("ACT_ALLOC"):
+            raws = [RawTensor(v.actions, envs["ACT_ALLOC"]) for _ in range(int(envs.get('RING', a.ring)))]
+            v._raw += raws
+            ring = [r.tensor for r in raws]
+        else:
+            ring = [torch.empty_like(v.actions) for _ in range(int(envs.get('RING', a.ring)))]
         for k, r_ in enumerate(ring):
             v.fill_random_actions(gstep=k, out=r_)
         return v, ring
@@ -90,7 +122,10 @@ def main():
             else:
                 v, ring = make(name)
                 times[name].append(timeit(v, ring))
+                torch.cuda.synchronize()
                 v.close()
+                for r in v._raw:
+                    r.free()
                 del v, ring
                 gc.collect()
     base = None
