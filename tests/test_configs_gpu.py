@@ -132,3 +132,14 @@ def test_full_size_properties_2pow20(hip):
     hi.rollout(64)
     assert_state_equal(sa[: n // 2], lo.get_state(), "lower half shard")
     assert_state_equal(sa[n // 2:], hi.get_state(), "upper half shard")
+
+
+def test_eight_million_envs_index_arithmetic(oracle, hip):
+    """2^23 envs (8x the metric's size; 1.2 GB of state planes): 32-bit index and
+    byte-offset arithmetic in the kernels, checked on sampled blocks incl. the last."""
+    n, seed = 1 << 23, 29
+    h = hip.DroneVec(n, seed=seed, task=1, device="cuda:0", horizon=20)
+    h.reset(seed)
+    run_steps(h, 12)
+    h.rollout(30)
+    check_against_sampled_oracle(oracle, h, 1, seed, 12, fused=30, horizon=20)
