@@ -8,9 +8,16 @@ submodule).
 import ctypes as C
 
 OBS_DIM = 20
+OBS_DIM_MAX = 24
 ACT_DIM = 4
 TASK_HOVER = 0
 TASK_WAYPOINT = 1
+TASK_SWARM = 2
+
+
+def obs_dim(task):
+    return OBS_DIM_MAX if task == TASK_SWARM else OBS_DIM
+
 BUFFERS_HOST = 0
 BUFFERS_DEVICE = 1
 
@@ -27,6 +34,7 @@ class DroneConfig(C.Structure):
         ("horizon", C.c_int32),
         ("substeps", C.c_int32),
         ("compact_done", C.c_int32),
+        ("agents_per_env", C.c_int32),
         ("dt", _F),
         ("mass", _F), ("arm", _F), ("ixx", _F), ("iyy", _F), ("izz", _F),
         ("k_thrust", _F), ("k_torque", _F), ("k_drag", _F), ("k_ang_damp", _F), ("gravity", _F),
@@ -35,6 +43,7 @@ class DroneConfig(C.Structure):
         ("hover_radius", _F), ("waypoint_radius", _F),
         ("wind_theta", _F), ("wind_sigma", _F), ("wind_max", _F),
         ("c_omega", _F), ("c_action", _F), ("crash_penalty", _F), ("progress_scale", _F), ("waypoint_bonus", _F),
+        ("collision_radius", _F), ("proximity_radius", _F), ("c_proximity", _F),
     ]
 
     def as_dict(self):
@@ -75,6 +84,7 @@ def state_row_dtype():
 _P = C.c_void_p
 SYMBOLS = {
     "drone_config_default": (None, [C.POINTER(DroneConfig), C.c_int]),
+    "drone_obs_dim": (C.c_int, [C.c_int]),
     "drone_vec_init": (_P, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(DroneConfig)]),
     "drone_vec_reset": (None, [_P, C.c_uint64]),
     "drone_vec_step": (None, [_P]),

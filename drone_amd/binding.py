@@ -93,7 +93,7 @@ class DroneVec:
         if device is None:
             self.torch_device = None
             self.cfg.buffer_kind = abi.BUFFERS_HOST
-            self.observations = np.zeros((n, abi.OBS_DIM), dtype=np.float32)
+            self.observations = np.zeros((n, abi.obs_dim(self.cfg.task)), dtype=np.float32)
             self.actions = np.zeros((n, abi.ACT_DIM), dtype=np.float32)
             self.rewards = np.zeros(n, dtype=np.float32)
             self.terminals = np.zeros(n, dtype=np.uint8)
@@ -107,7 +107,7 @@ class DroneVec:
             self.torch_device = dev
             self.cfg.buffer_kind = abi.BUFFERS_DEVICE
             self.cfg.device = dev.index if dev.index is not None else torch.cuda.current_device()
-            self.observations = torch.zeros((n, abi.OBS_DIM), dtype=torch.float32, device=dev)
+            self.observations = torch.zeros((n, abi.obs_dim(self.cfg.task)), dtype=torch.float32, device=dev)
             self.actions = torch.zeros((n, abi.ACT_DIM), dtype=torch.float32, device=dev)
             self.rewards = torch.zeros(n, dtype=torch.float32, device=dev)
             self.terminals = torch.zeros(n, dtype=torch.uint8, device=dev)

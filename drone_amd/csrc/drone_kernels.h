@@ -17,7 +17,7 @@ struct DeviceView {
     uint32_t stride;     // float4 elements between consecutive planes (>= n_pad; padded so planes start on different HBM channels)
     const uint32_t* kp;  // KParams in HBM (kParamWords words) — read only by the LDS-staging build
     const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)
-    float* obs;          // [n][20]
+    float* obs;          // [n][20] (24 for the swarm task)
     const float* act;    // [n][4]
     float* rew;          // [n]
     unsigned char* term; // [n]
@@ -31,7 +31,7 @@ struct DeviceView {
 #endif
 constexpr int kBlock = DRONE_BLOCK;
 
-hipError_t launch_reset(const DeviceView& v, hipStream_t s);
+hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s);
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s);
 hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s);
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s);

@@ -56,7 +56,8 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kObsVec = DRONE_OBS_DIM / 4;     // float4 per observation row = 5
+constexpr int kObsVecMax = DRONE_OBS_DIM_MAX / 4;  // float4 per observation row: 5 (tasks 0, 1) or 6 (swarm)
+template <int TASK> constexpr int obs_vec() { return TASK == DRONE_TASK_SWARM ? 6 : 5; }
 constexpr int kFlagLanes = kBlock / 16;        // lanes that write one flag array of a workgroup, 16 B each
 static_assert(kBlock % kWave == 0 && 2 * kFlagLanes <= kWave, "workgroup must be 64..512 threads");
 
@@ -141,7 +142,7 @@ struct StepArgs {
 
 // LDS of one workgroup
 struct Shared {
-    float4 obs_tile[kWavesPerBlock][kWave * kObsVec];  // wave-private observation tiles
+    float4 obs_tile[kWavesPerBlock][kWave * kObsVecMax];  // wave-private observation tiles
     uint64_t masks[2][kWavesPerBlock];                 // ballot masks: [terminal | truncation][wave]
 #if DRONE_PARAMS_IN_LDS
     KParams kp;
@@ -165,7 +166,8 @@ __device__ __forceinline__ uint32_t spread4(uint32_t nib) { return ((nib & 0xFu)
 // The whole workgroup's outputs for its 256 drones: observation rows, rewards
 // are already stored by the caller; here obs + terminal/truncation bytes.
 // Every thread of the workgroup must call this (it contains the barrier).
-__device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, uint32_t flags_aligned, const float (&o)[DRONE_OBS_DIM],
+template <int OBSV>
+__device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, uint32_t flags_aligned, const float (&o)[DRONE_OBS_DIM_MAX],
                                               bool term, bool trunc, uint32_t i, uint32_t block_base) {
     const uint32_t n = v.n;
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -180,17 +182,17 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
     }
     float4* tile = sh.obs_tile[wave];
 #pragma unroll
-    for (int k = 0; k < kObsVec; k++)  // row-major [lane][20]: ds_write_b128, conflict-free at the 80-B row stride
-        tile[lane * kObsVec + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    for (int k = 0; k < OBSV; k++)  // row-major [lane][4*OBSV]: ds_write_b128, conflict-free at the 80-B row stride
+        tile[lane * OBSV + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
     __syncthreads();
 
     if (wave_base < n) {  // read the tile back flat: 5 x 1 KiB contiguous per wave
         const uint32_t rows = n - wave_base < (uint32_t)kWave ? n - wave_base : (uint32_t)kWave;
-        float4* dst = reinterpret_cast<float4*>(v.obs + (size_t)wave_base * DRONE_OBS_DIM);
+        float4* dst = reinterpret_cast<float4*>(v.obs + (size_t)wave_base * (4 * OBSV));
 #pragma unroll
-        for (int k = 0; k < kObsVec; k++) {
+        for (int k = 0; k < OBSV; k++) {
             const uint32_t j = k * kWave + lane;
-            if (j < rows * kObsVec) out_store(&dst[j], tile[j]);
+            if (j < rows * OBSV) out_store(&dst[j], tile[j]);
         }
     }
 
@@ -206,6 +208,44 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
     } else if (valid) {
         v.term[i] = term ? 1 : 0;
         v.trunc[i] = trunc ? 1 : 0;
+    }
+}
+
+// SPEC.md §10: nearest neighbour among the lanes of this drone's swarm — the
+// A = P.agents consecutive lanes starting at lane & ~(A-1). One ds_bpermute per
+// coordinate and neighbour; every lane of the wave takes part (no divergence).
+__device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L, float& nn_d2, float (&nn_e)[3]) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), mask = P.agents - 1u, base = lane & ~mask;
+    nearest_neighbour(P, [&](uint32_t d, float (&e)[3]) {
+        const int src = (int)(base | ((lane + d) & mask));
+        e[0] = __shfl(L.s.p[0], src) - L.s.p[0];
+        e[1] = __shfl(L.s.p[1], src) - L.s.p[1];
+        e[2] = __shfl(L.s.p[2], src) - L.s.p[2];
+    }, nn_d2, nn_e);
+}
+
+// steps 1-9 of one env step for any task (the swarm task looks at its neighbours in between)
+template <int TASK>
+__device__ __forceinline__ void step_any(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
+    if (TASK == DRONE_TASK_SWARM) {
+        StepCtx ctx;
+        lane_integrate<TASK>(P, L, act, env, gstep, ctx);
+        float nn_d2, nn_e[3];
+        swarm_neighbour(P, L, nn_d2, nn_e);
+        lane_finish<TASK>(P, L, env, ctx, nn_d2, out);
+    } else {
+        lane_step<TASK>(P, L, act, env, gstep, out);
+    }
+}
+
+// the observation row of the (possibly fresh) state
+template <int TASK>
+__device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM_MAX]) {
+    lane_obs(P, L, o);
+    if (TASK == DRONE_TASK_SWARM) {
+        float nn_d2, nn_e[3];
+        swarm_neighbour(P, L, nn_d2, nn_e);  // on the positions after resets
+        lane_obs_neighbour(P, L, nn_d2, nn_e, o);
     }
 }
 
@@ -255,7 +295,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         act[0] = av.x; act[1] = av.y; act[2] = av.z; act[3] = av.w;
     }
     StepOut out;
-    lane_step<TASK>(P, L, act, P.env_offset + i, a.gstep, out);
+    step_any<TASK>(P, L, act, P.env_offset + i, a.gstep, out);
     const bool done = valid && (out.oob || out.trunc);
 
     if (valid) {
@@ -283,14 +323,15 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         }
     }
 
-    float o[DRONE_OBS_DIM];
-    lane_obs(P, L, o);
-    write_outputs(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base);
+    float o[DRONE_OBS_DIM_MAX];
+    obs_any<TASK>(P, L, o);
+    write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base);
 }
 
 // =====================================================================
 // vec_reset (SPEC.md §6). Grid covers n_pad so the padding lanes are valid too.
 // =====================================================================
+template <int TASK>
 __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -305,9 +346,9 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     a.v.planes[kL1 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) a.v.rew[i] = 0.0f;
     if (a.v.done_count && i < 2) a.v.done_count[i] = 0u;
-    float o[DRONE_OBS_DIM];
-    lane_obs(P, L, o);
-    write_outputs(sh, a.v, a.flags_aligned, o, false, false, i, block_base);
+    float o[DRONE_OBS_DIM_MAX];
+    obs_any<TASK>(P, L, o);
+    write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, false, false, i, block_base);
 }
 
 // =====================================================================
@@ -344,7 +385,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, a.gstep + t, act);
         StepOut out;
-        lane_step<TASK>(P, L, act, env, a.gstep + t, out);
+        step_any<TASK>(P, L, act, env, a.gstep + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -359,9 +400,9 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
             a.v.planes[kL1 * np + i] = l1;
         }
     }
-    float o[DRONE_OBS_DIM];
-    lane_obs(P, L, o);
-    write_outputs(sh, a.v, a.flags_aligned, o, any_term, any_trunc, i, block_base);
+    float o[DRONE_OBS_DIM_MAX];
+    obs_any<TASK>(P, L, o);
+    write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, any_term, any_trunc, i, block_base);
 }
 
 // =====================================================================
@@ -428,8 +469,10 @@ inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
 
-hipError_t launch_reset(const DeviceView& v, hipStream_t s) {
-    drone_reset_kernel<<<dim3(v.n_pad / kBlock), dim3(kBlock), 0, s>>>(make_args(v, 0));
+hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
+    const dim3 g(v.n_pad / kBlock), b(kBlock);
+    if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(make_args(v, 0));
+    else drone_reset_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(make_args(v, 0));
     return hipGetLastError();
 }
 
@@ -440,6 +483,9 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_
     if (task == DRONE_TASK_HOVER) {
         if (compact) drone_step_kernel<DRONE_TASK_HOVER, true><<<g, b, 0, s>>>(a);
         else drone_step_kernel<DRONE_TASK_HOVER, false><<<g, b, 0, s>>>(a);
+    } else if (task == DRONE_TASK_SWARM) {
+        if (compact) drone_step_kernel<DRONE_TASK_SWARM, true><<<g, b, 0, s>>>(a);
+        else drone_step_kernel<DRONE_TASK_SWARM, false><<<g, b, 0, s>>>(a);
     } else {
         if (compact) drone_step_kernel<DRONE_TASK_WAYPOINT, true><<<g, b, 0, s>>>(a);
         else drone_step_kernel<DRONE_TASK_WAYPOINT, false><<<g, b, 0, s>>>(a);
@@ -451,6 +497,7 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     const StepArgs a = make_args(v, gstep0);
     const dim3 g(grid_for(v.n)), b(kBlock);
     if (task == DRONE_TASK_HOVER) drone_rollout_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(a, horizon);
+    else if (task == DRONE_TASK_SWARM) drone_rollout_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(a, horizon);
     else drone_rollout_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(a, horizon);
     return hipGetLastError();
 }

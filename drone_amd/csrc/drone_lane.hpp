@@ -148,16 +148,23 @@ DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, f
     a[3] = s16(h1 >> 16);
 }
 
-// SPEC.md §5 steps 1–9 (everything but the observation).
+// What lane_integrate hands to lane_finish.
+struct StepCtx {
+    float a2;         // |clamped action|^2
+    float prev_dist;  // waypoint task: distance before integrating
+};
+
+// SPEC.md §5 steps 1–4: actions, wind, RK4, renormalise, clamp, tick.
 template <int TASK>
-DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
+DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepCtx& ctx) {
     float a[4], ct[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         a[i] = clampc(act[i], -1.0f, 1.0f);
         ct[i] = (P.half_max_rpm * (a[i] + 1.0f)) * P.inv_tau;
     }
-    float prev_dist = 0.0f;
+    ctx.a2 = fma_(a[0], a[0], fma_(a[1], a[1], fma_(a[2], a[2], a[3] * a[3])));
+    ctx.prev_dist = 0.0f;
     if (TASK == DRONE_TASK_WAYPOINT) {
         const uint32_t b = rng_base(P.key_wind, env, gstep);
 #pragma unroll
@@ -167,7 +174,7 @@ DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32
             const float xi = (float)((int)sum - 510);
             L.wind[i] = clampc(fma_(P.wind_decay, L.wind[i], P.wind_gain * xi), -P.wind_max, P.wind_max);
         }
-        prev_dist = target_dist(L);
+        ctx.prev_dist = target_dist(L);
     }
 
     for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, ct, L.wind);
@@ -186,21 +193,47 @@ DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32
         for (int i = 0; i < 4; i++) L.s.r[i] = __builtin_fminf(L.s.r[i] < 0.0f ? 0.0f : L.s.r[i], P.max_rpm);
     }
     L.tick += 1u;
+}
 
+// SPEC.md §10: nearest neighbour among the A agents of a swarm. `other(d, e)`
+// yields e = p_j - p_i for the agent d places further round the swarm — lane
+// shuffles in the kernels, an array walk in the host test harness.
+template <class Other>
+DRONE_FN void nearest_neighbour(const KParams& P, Other other, float& nn_d2, float (&nn_e)[3]) {
+    nn_d2 = P.nn_far2;
+    nn_e[0] = nn_e[1] = nn_e[2] = 0.0f;
+    for (uint32_t d = 1; d < P.agents; d++) {
+        float e[3];
+        other(d, e);
+        const float d2 = fma_(e[0], e[0], fma_(e[1], e[1], e[2] * e[2]));
+        if (d2 < nn_d2) {
+            nn_d2 = d2;
+            nn_e[0] = e[0];
+            nn_e[1] = e[1];
+            nn_e[2] = e[2];
+        }
+    }
+}
+
+// SPEC.md §5 steps 5–9 (§10 steps 6–7 for the swarm task): distance, bounds,
+// reward, episode end and reset. `nn_d2` is read only by the swarm task.
+template <int TASK>
+DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx& ctx, float nn_d2, StepOut& out) {
     const float dist = target_dist(L);
-    const bool oob = !(fabsf(L.s.p[0]) <= P.bound) || !(fabsf(L.s.p[1]) <= P.bound) || !(fabsf(L.s.p[2]) <= P.bound);
+    bool oob = !(fabsf(L.s.p[0]) <= P.bound) || !(fabsf(L.s.p[1]) <= P.bound) || !(fabsf(L.s.p[2]) <= P.bound);
+    if (TASK == DRONE_TASK_SWARM) oob = oob || (nn_d2 < P.coll_r2);  // crash = left the box or collided
     const bool trunc = !oob && L.tick >= P.horizon;
 
     const float w2 = fma_(L.s.o[0], L.s.o[0], fma_(L.s.o[1], L.s.o[1], L.s.o[2] * L.s.o[2]));
-    const float a2 = fma_(a[0], a[0], fma_(a[1], a[1], fma_(a[2], a[2], a[3] * a[3])));
-    const float pen = fma_(P.c_omega, w2, P.c_action * a2);
+    const float pen = fma_(P.c_omega, w2, P.c_action * ctx.a2);
     float r;
     bool target_changed = false;
-    if (TASK == DRONE_TASK_HOVER) {
+    if (TASK != DRONE_TASK_WAYPOINT) {
         r = fma_(-P.half_inv_bound, dist, 1.0f) - pen;
         if (dist < P.hover_radius) L.score_count += 1u;
+        if (TASK == DRONE_TASK_SWARM) r = r - P.c_proximity * __builtin_fmaxf(0.0f, fma_(-nn_d2, P.inv_prox_r2, 1.0f));
     } else {
-        r = P.progress_scale * (prev_dist - dist) - pen;
+        r = P.progress_scale * (ctx.prev_dist - dist) - pen;
         if (!oob && dist < P.waypoint_radius) {
             r += P.waypoint_bonus;
             L.score_count += 1u;
@@ -219,7 +252,7 @@ DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32
     out.perf = out.score = out.ep_return = out.ep_len = 0.0f;
     if (oob || trunc) {
         float score, perf;
-        if (TASK == DRONE_TASK_HOVER) {
+        if (TASK != DRONE_TASK_WAYPOINT) {
             score = (float)L.score_count / (float)L.tick;
             perf = score;
         } else {
@@ -237,8 +270,16 @@ DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32
     out.target_changed = target_changed;
 }
 
+// Single-agent tasks: the whole of SPEC.md §5 steps 1–9.
+template <int TASK>
+DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
+    StepCtx ctx;
+    lane_integrate<TASK>(P, L, act, env, gstep, ctx);
+    lane_finish<TASK>(P, L, env, ctx, 0.0f, out);
+}
+
 // SPEC.md §7
-DRONE_FN void lane_obs(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM]) {
+DRONE_FN void lane_obs(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM_MAX]) {
     const float w = L.s.q[0], x = L.s.q[1], y = L.s.q[2], z = L.s.q[3];
     const float r00 = fma_(-2.0f, fma_(y, y, z * z), 1.0f);
     const float r01 = 2.0f * fma_(x, y, -(w * z));
@@ -265,6 +306,18 @@ DRONE_FN void lane_obs(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM
     o[16] = fma_(r02, ex, fma_(r12, ey, r22 * ez)) * P.half_inv_bound;
 #pragma unroll
     for (int i = 0; i < 3; i++) o[17 + i] = L.s.p[i] * P.inv_bound;
+}
+
+// SPEC.md §10 step 10: the four neighbour observations (rows of 24 floats).
+DRONE_FN void lane_obs_neighbour(const KParams& P, const Lane& L, float nn_d2, const float (&e)[3], float (&o)[DRONE_OBS_DIM_MAX]) {
+    const float w = L.s.q[0], x = L.s.q[1], y = L.s.q[2], z = L.s.q[3];
+    const float r00 = fma_(-2.0f, fma_(y, y, z * z), 1.0f), r01 = 2.0f * fma_(x, y, -(w * z)), r02 = 2.0f * fma_(x, z, w * y);
+    const float r10 = 2.0f * fma_(x, y, w * z), r11 = fma_(-2.0f, fma_(x, x, z * z), 1.0f), r12 = 2.0f * fma_(y, z, -(w * x));
+    const float r20 = 2.0f * fma_(x, z, -(w * y)), r21 = 2.0f * fma_(y, z, w * x), r22 = fma_(-2.0f, fma_(x, x, y * y), 1.0f);
+    o[20] = fma_(r00, e[0], fma_(r10, e[1], r20 * e[2])) * P.half_inv_bound;
+    o[21] = fma_(r01, e[0], fma_(r11, e[1], r21 * e[2])) * P.half_inv_bound;
+    o[22] = fma_(r02, e[0], fma_(r12, e[1], r22 * e[2])) * P.half_inv_bound;
+    o[23] = (nn_d2 * P.inv_bound) * P.inv_bound;
 }
 
 }  // namespace drone

@@ -37,7 +37,7 @@ enum Plane : int {
     kNumPlanes = 9
 };
 
-// Everything a lane needs that is the same for all lanes: 52 words. Reaches
+// Everything a lane needs that is the same for all lanes: 56 words. Reaches
 // the lanes through the kernarg segment (scalar loads) or, with
 // -DDRONE_PARAMS_IN_LDS=1, staged HBM -> LDS once per workgroup and read by
 // broadcast ds_read (drone_kernels.hip).
@@ -57,14 +57,16 @@ struct KParams {
     float hover_radius, waypoint_radius;
     float wind_decay, wind_gain, wind_max;
     float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
+    float coll_r2, inv_prox_r2, nn_far2, c_proximity;  // task 2 (SPEC.md §10)
     // integers
     uint32_t horizon, substeps;
     uint32_t key_reset, key_action, key_wind, key_waypoint;
     uint32_t env_offset;
-    uint32_t pad_[2];
+    uint32_t agents;  // drones per swarm (task 2), else 1
+    uint32_t pad_;
 };
-static_assert(sizeof(KParams) == 52 * 4, "KParams is passed / staged as 52 words");
-constexpr int kParamWords = 52;
+static_assert(sizeof(KParams) == 56 * 4, "KParams is passed / staged as 56 words");
+constexpr int kParamWords = 56;
 
 // ---- SPEC.md §2: counter RNG ----
 DRONE_FN uint32_t hash32(uint32_t x) {
@@ -135,6 +137,10 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.crash_penalty = c.crash_penalty;
     p.progress_scale = c.progress_scale;
     p.waypoint_bonus = c.waypoint_bonus;
+    p.coll_r2 = c.collision_radius * c.collision_radius;
+    p.inv_prox_r2 = 1.0f / (c.proximity_radius * c.proximity_radius);
+    p.nn_far2 = (4.0f * c.bound) * (4.0f * c.bound);
+    p.c_proximity = c.c_proximity;
     p.horizon = (uint32_t)c.horizon;
     p.substeps = (uint32_t)c.substeps;
     p.key_reset = stream_key(seed, kReset);
@@ -142,7 +148,8 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.key_wind = stream_key(seed, kWind);
     p.key_waypoint = stream_key(seed, kWaypoint);
     p.env_offset = c.env_offset;
-    p.pad_[0] = p.pad_[1] = 0;
+    p.agents = c.task == DRONE_TASK_SWARM ? (uint32_t)c.agents_per_env : 1u;
+    p.pad_ = 0;
 }
 
 }  // namespace drone

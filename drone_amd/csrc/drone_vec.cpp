@@ -105,7 +105,13 @@ bool validate(const DroneConfig* c, int num_envs) {
     if (!c) { set_err("config is NULL"); return false; }
     if (c->struct_size != sizeof(DroneConfig)) { set_err("DroneConfig.struct_size %u != %zu", c->struct_size, sizeof(DroneConfig)); return false; }
     if (num_envs <= 0) { set_err("num_envs must be positive"); return false; }
-    if (c->task != DRONE_TASK_HOVER && c->task != DRONE_TASK_WAYPOINT) { set_err("unknown task %d", c->task); return false; }
+    if (c->task != DRONE_TASK_HOVER && c->task != DRONE_TASK_WAYPOINT && c->task != DRONE_TASK_SWARM) { set_err("unknown task %d", c->task); return false; }
+    if (c->task == DRONE_TASK_SWARM) {
+        const int A = c->agents_per_env;
+        if (A < 1 || A > 64 || (A & (A - 1))) { set_err("agents_per_env must be a power of two in [1, 64], got %d", A); return false; }
+        if (num_envs % A || c->env_offset % (uint32_t)A) { set_err("num_envs and env_offset must be multiples of agents_per_env (%d)", A); return false; }
+        if (!(c->proximity_radius > 0.0f)) { set_err("proximity_radius must be positive"); return false; }
+    }
     if (c->buffer_kind != DRONE_BUFFERS_HOST && c->buffer_kind != DRONE_BUFFERS_DEVICE) { set_err("unknown buffer_kind %d", c->buffer_kind); return false; }
     if (c->substeps < 1 || c->horizon < 1) { set_err("substeps and horizon must be >= 1"); return false; }
     if (!(c->dt > 0.0f) || !(c->mass > 0.0f) || !(c->ixx > 0.0f) || !(c->iyy > 0.0f) || !(c->izz > 0.0f) || !(c->motor_tau > 0.0f) ||
@@ -128,7 +134,7 @@ bool device_to_host_outputs(DroneVec* v) {
         return true;
     }
     const size_t n = (size_t)v->n;
-    HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * DRONE_OBS_DIM * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipMemcpyAsync(v->u_rew, v->d_rew, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipMemcpyAsync(v->u_term, v->d_term, n, hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipMemcpyAsync(v->u_trunc, v->d_trunc, n, hipMemcpyDeviceToHost, v->stream), return false);
@@ -229,7 +235,13 @@ void drone_config_default(DroneConfig* c, int task) {
     c->crash_penalty = 1.0f;
     c->progress_scale = 1.0f;
     c->waypoint_bonus = 1.0f;
+    c->agents_per_env = task == DRONE_TASK_SWARM ? 8 : 1;
+    c->collision_radius = 0.15f;
+    c->proximity_radius = 1.0f;
+    c->c_proximity = 0.5f;
 }
+
+int drone_obs_dim(int task) { return task == DRONE_TASK_SWARM ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
 
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, unsigned char* terminals,
                          unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {
@@ -273,12 +285,12 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         INIT_TRY(hipMemsetAsync(v->dv.done_count, 0, sizeof(uint32_t) * 2, v->stream));
     }
     if (v->host_buffers) {
-        INIT_TRY(hipMalloc((void**)&v->d_obs, n * DRONE_OBS_DIM * sizeof(float)));
+        INIT_TRY(hipMalloc((void**)&v->d_obs, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float)));
         INIT_TRY(hipMalloc((void**)&v->d_act, n * DRONE_ACT_DIM * sizeof(float)));
         INIT_TRY(hipMalloc((void**)&v->d_rew, n * sizeof(float)));
         INIT_TRY(hipMalloc((void**)&v->d_term, n));
         INIT_TRY(hipMalloc((void**)&v->d_trunc, n));
-        try_register(v, 0, observations, n * DRONE_OBS_DIM * sizeof(float));
+        try_register(v, 0, observations, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float));
         try_register(v, 1, actions, n * DRONE_ACT_DIM * sizeof(float));
         try_register(v, 2, rewards, n * sizeof(float));
         try_register(v, 3, terminals, n);
@@ -323,7 +335,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->seed = seed;
     v->gstep = 0;
     if (!upload_params(v)) return;
-    HIP_TRY(launch_reset(v->dv, v->stream), return);
+    HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream), return);
     if (v->host_buffers) device_to_host_outputs(v);
 }
 

@@ -28,10 +28,10 @@ class Box:
 
 class Drone:
     def __init__(self, num_envs=1024, task="hover", device=None, seed=0, log_interval=128, **config):
-        task_id = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT}[task] if isinstance(task, str) else int(task)
+        task_id = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT, "swarm": abi.TASK_SWARM}[task] if isinstance(task, str) else int(task)
         self.vec = binding.DroneVec(num_envs, seed=seed, task=task_id, device=device, **config)
         self.num_agents = self.vec.num_envs
-        self.single_observation_space = Box(-np.inf, np.inf, (abi.OBS_DIM,))
+        self.single_observation_space = Box(-np.inf, np.inf, (abi.obs_dim(task_id),))
         self.single_action_space = Box(-1.0, 1.0, (abi.ACT_DIM,))
         self.log_interval = int(log_interval)
         self.seed = seed

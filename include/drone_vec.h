@@ -29,11 +29,13 @@
 extern "C" {
 #endif
 
-#define DRONE_OBS_DIM 20
+#define DRONE_OBS_DIM 20     /* observation floats per env row, tasks 0 and 1 */
+#define DRONE_OBS_DIM_MAX 24 /* task 2 appends the nearest neighbour (3 + 1) */
 #define DRONE_ACT_DIM 4
 
 #define DRONE_TASK_HOVER 0
 #define DRONE_TASK_WAYPOINT 1 /* waypoint tracking with OU wind gusts */
+#define DRONE_TASK_SWARM 2    /* agents_per_env drones per env, coupled by a nearest-neighbour term (SPEC.md §10) */
 
 #define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory: registered + mapped, the kernel accesses them over PCIe (fallback: H2D, kernel, D2H); step ends with a sync */
 #define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
@@ -48,6 +50,7 @@ typedef struct DroneConfig {
     int32_t horizon;
     int32_t substeps;
     int32_t compact_done; /* 1: also build the compacted done-id list each step */
+    int32_t agents_per_env; /* task 2: power of two in [1, 64]; num_envs and env_offset must be multiples of it */
     float dt;
     float mass, arm, ixx, iyy, izz;
     float k_thrust, k_torque, k_drag, k_ang_damp, gravity;
@@ -56,6 +59,7 @@ typedef struct DroneConfig {
     float hover_radius, waypoint_radius;
     float wind_theta, wind_sigma, wind_max;
     float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
+    float collision_radius, proximity_radius, c_proximity; /* task 2 */
 } DroneConfig;
 
 /* Aggregated episode statistics since the previous drone_vec_log (SPEC.md §8). */
@@ -82,7 +86,10 @@ typedef struct DroneVec DroneVec;
 
 void drone_config_default(DroneConfig* cfg, int task);
 
-/* observations [N][20] f32, actions [N][4] f32, rewards [N] f32,
+/* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM. */
+int drone_obs_dim(int task);
+
+/* observations [N][drone_obs_dim(task)] f32, actions [N][4] f32, rewards [N] f32,
  * terminals [N] u8, truncations [N] u8 — owned by the caller, never freed
  * here. Returns NULL on failure (see drone_last_error). Does not reset. */
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards,

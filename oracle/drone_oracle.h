@@ -46,6 +46,7 @@ typedef struct Params {
     float inv_max_vel, inv_max_omega, inv_max_rpm;
     float inv_bound, half_inv_bound;
     float wind_decay, wind_gain;
+    float coll_r2, inv_prox_r2, nn_far2;
 } Params;
 
 static inline void params_derive(const DroneConfig* c, Params* p) {
@@ -82,6 +83,9 @@ static inline void params_derive(const DroneConfig* c, Params* p) {
     p->half_inv_bound = 0.5f * p->inv_bound;
     p->wind_decay = 1.0f - c->wind_theta * c->dt;
     p->wind_gain = (c->wind_sigma * sqrtf(c->dt)) * 0.0067658754f;
+    p->coll_r2 = c->collision_radius * c->collision_radius;
+    p->inv_prox_r2 = 1.0f / (c->proximity_radius * c->proximity_radius);
+    p->nn_far2 = (4.0f * c->bound) * (4.0f * c->bound);
 }
 
 /* SPEC.md §2 */
@@ -135,6 +139,7 @@ typedef struct Drone {
     float ep_return;
     uint32_t tick, episode, score_count;
     uint32_t env_id; /* global id */
+    float scratch_a2, scratch_prev_dist; /* carried from step_integrate to step_finish */
     /* shared, read-only */
     const DroneConfig* cfg;
     const Params* par;
@@ -295,8 +300,9 @@ static inline void c_reset(Drone* env) {
     env->truncations[0] = 0;
 }
 
-/* SPEC.md §5 */
-static inline void c_step(Drone* env) {
+/* SPEC.md §5 steps 1-5: actions, wind, integration, tick, distance. What the
+ * later phases need is parked in the env (scratch fields). */
+static inline void step_integrate(Drone* env) {
     const DroneConfig* c = env->cfg;
     const Params* p = env->par;
     State* s = &env->s;
@@ -306,7 +312,8 @@ static inline void c_step(Drone* env) {
         const float cmd = p->half_max_rpm * (a[i] + 1.0f);
         ct[i] = cmd * p->inv_tau;
     }
-    float prev_dist = 0.0f;
+    env->scratch_a2 = fmaf(a[0], a[0], fmaf(a[1], a[1], fmaf(a[2], a[2], a[3] * a[3])));
+    env->scratch_prev_dist = 0.0f;
     if (c->task == DRONE_TASK_WAYPOINT) {
         const uint32_t b = rng_base(env->keys[STREAM_WIND], env->env_id, *env->gstep);
         for (uint32_t i = 0; i < 3; i++) {
@@ -315,9 +322,8 @@ static inline void c_step(Drone* env) {
             const float xi = (float)((int)sum - 510);
             env->wind[i] = clampc(fmaf(p->wind_decay, env->wind[i], p->wind_gain * xi), -c->wind_max, c->wind_max);
         }
-        prev_dist = target_dist(env);
+        env->scratch_prev_dist = target_dist(env);
     }
-
     for (int k = 0; k < c->substeps; k++) rk4_substep(env, ct);
     {
         float* q = s->quat;
@@ -329,20 +335,48 @@ static inline void c_step(Drone* env) {
         for (int i = 0; i < 4; i++) s->rpm[i] = fminf(s->rpm[i] < 0.0f ? 0.0f : s->rpm[i], c->max_rpm);
     }
     env->tick += 1;
+}
 
+/* SPEC.md §10: nearest neighbour of agent `i` among the `A` agents of its swarm. */
+static inline void neighbour(const Drone* swarm, int A, int i, float* nn_d2, float nn_e[3]) {
+    const Params* p = swarm[i].par;
+    float best = p->nn_far2;
+    nn_e[0] = nn_e[1] = nn_e[2] = 0.0f;
+    for (int d = 1; d < A; d++) {
+        const Drone* o = &swarm[(i + d) % A];
+        const float ex = o->s.pos[0] - swarm[i].s.pos[0];
+        const float ey = o->s.pos[1] - swarm[i].s.pos[1];
+        const float ez = o->s.pos[2] - swarm[i].s.pos[2];
+        const float d2 = fmaf(ex, ex, fmaf(ey, ey, ez * ez));
+        if (d2 < best) {
+            best = d2;
+            nn_e[0] = ex;
+            nn_e[1] = ey;
+            nn_e[2] = ez;
+        }
+    }
+    *nn_d2 = best;
+}
+
+/* SPEC.md §5 steps 5-9 (+ §10 steps 6-7 for the swarm task). */
+static inline void step_finish(Drone* env, float nn_d2) {
+    const DroneConfig* c = env->cfg;
+    const Params* p = env->par;
+    State* s = &env->s;
     const float dist = target_dist(env);
-    const int oob = !(fabsf(s->pos[0]) <= c->bound) || !(fabsf(s->pos[1]) <= c->bound) || !(fabsf(s->pos[2]) <= c->bound);
+    int oob = !(fabsf(s->pos[0]) <= c->bound) || !(fabsf(s->pos[1]) <= c->bound) || !(fabsf(s->pos[2]) <= c->bound);
+    if (c->task == DRONE_TASK_SWARM) oob = oob || (nn_d2 < p->coll_r2); /* crash = out of the box or collided */
     const int trunc = !oob && env->tick >= (uint32_t)c->horizon;
 
     const float w2 = fmaf(s->omega[0], s->omega[0], fmaf(s->omega[1], s->omega[1], s->omega[2] * s->omega[2]));
-    const float a2 = fmaf(a[0], a[0], fmaf(a[1], a[1], fmaf(a[2], a[2], a[3] * a[3])));
-    const float pen = fmaf(c->c_omega, w2, c->c_action * a2);
+    const float pen = fmaf(c->c_omega, w2, c->c_action * env->scratch_a2);
     float r;
-    if (c->task == DRONE_TASK_HOVER) {
+    if (c->task != DRONE_TASK_WAYPOINT) {
         r = fmaf(-p->half_inv_bound, dist, 1.0f) - pen;
         if (dist < c->hover_radius) env->score_count += 1;
+        if (c->task == DRONE_TASK_SWARM) r = r - c->c_proximity * fmaxf(0.0f, fmaf(-nn_d2, p->inv_prox_r2, 1.0f));
     } else {
-        r = c->progress_scale * (prev_dist - dist) - pen;
+        r = c->progress_scale * (env->scratch_prev_dist - dist) - pen;
         if (!oob && dist < c->waypoint_radius) {
             r += c->waypoint_bonus;
             env->score_count += 1;
@@ -360,7 +394,7 @@ static inline void c_step(Drone* env) {
 
     if (oob || trunc) {
         float score, perf;
-        if (c->task == DRONE_TASK_HOVER) {
+        if (c->task != DRONE_TASK_WAYPOINT) {
             score = (float)env->score_count / (float)env->tick;
             perf = score;
         } else {
@@ -376,7 +410,47 @@ static inline void c_step(Drone* env) {
         env->episode += 1;
         reset_state(env);
     }
+}
+
+/* SPEC.md §10 step 10: the four neighbour observations of agent `i`. */
+static inline void swarm_observations(Drone* swarm, int A, int i) {
+    Drone* env = &swarm[i];
+    const Params* p = env->par;
+    float nn_d2, e[3];
+    neighbour(swarm, A, i, &nn_d2, e);
+    const float w = env->s.quat[0], x = env->s.quat[1], y = env->s.quat[2], z = env->s.quat[3];
+    const float r00 = fmaf(-2.0f, fmaf(y, y, z * z), 1.0f), r01 = 2.0f * fmaf(x, y, -(w * z)), r02 = 2.0f * fmaf(x, z, w * y);
+    const float r10 = 2.0f * fmaf(x, y, w * z), r11 = fmaf(-2.0f, fmaf(x, x, z * z), 1.0f), r12 = 2.0f * fmaf(y, z, -(w * x));
+    const float r20 = 2.0f * fmaf(x, z, -(w * y)), r21 = 2.0f * fmaf(y, z, w * x), r22 = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
+    float* o = env->observations;
+    o[20] = fmaf(r00, e[0], fmaf(r10, e[1], r20 * e[2])) * p->half_inv_bound;
+    o[21] = fmaf(r01, e[0], fmaf(r11, e[1], r21 * e[2])) * p->half_inv_bound;
+    o[22] = fmaf(r02, e[0], fmaf(r12, e[1], r22 * e[2])) * p->half_inv_bound;
+    o[23] = (nn_d2 * p->inv_bound) * p->inv_bound;
+}
+
+/* One step of a single-agent env (tasks 0 and 1): SPEC.md §5. */
+static inline void c_step(Drone* env) {
+    step_integrate(env);
+    step_finish(env, 0.0f);
     compute_observations(env);
+}
+
+/* One step of a swarm of A agents (task 2): SPEC.md §10. */
+static inline void c_step_swarm(Drone* swarm, int A) {
+    float nn_d2[64], e[3];
+    for (int i = 0; i < A; i++) step_integrate(&swarm[i]);
+    for (int i = 0; i < A; i++) neighbour(swarm, A, i, &nn_d2[i], e); /* all on post-integration positions */
+    for (int i = 0; i < A; i++) step_finish(&swarm[i], nn_d2[i]);
+    for (int i = 0; i < A; i++) {
+        compute_observations(&swarm[i]);
+        swarm_observations(swarm, A, i);
+    }
+}
+
+static inline void c_reset_swarm(Drone* swarm, int A) {
+    for (int i = 0; i < A; i++) c_reset(&swarm[i]);
+    for (int i = 0; i < A; i++) swarm_observations(swarm, A, i);
 }
 
 #endif /* DRONE_ORACLE_H */

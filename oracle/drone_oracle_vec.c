@@ -43,6 +43,7 @@ void oracle_config_default(DroneConfig* c, int task) {
     c->horizon = 1024;
     c->substeps = 1;
     c->compact_done = 0;
+    c->agents_per_env = task == DRONE_TASK_SWARM ? 8 : 1;
     c->dt = 0.01f;
     c->mass = 0.027f;
     c->arm = 0.0397f;
@@ -72,7 +73,12 @@ void oracle_config_default(DroneConfig* c, int task) {
     c->crash_penalty = 1.0f;
     c->progress_scale = 1.0f;
     c->waypoint_bonus = 1.0f;
+    c->collision_radius = 0.15f;
+    c->proximity_radius = 1.0f;
+    c->c_proximity = 0.5f;
 }
+
+int oracle_obs_dim(int task) { return task == DRONE_TASK_SWARM ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
 
 static void set_keys(OracleVec* v, uint64_t seed) {
     for (uint32_t s = 0; s < 4; s++) v->keys[s] = stream_key(seed, s);
@@ -82,6 +88,10 @@ OracleVec* oracle_vec_init(float* observations, float* actions, float* rewards, 
                            unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {
     if (!cfg || cfg->struct_size != sizeof(DroneConfig) || num_envs <= 0) return NULL;
     if (cfg->substeps < 1 || cfg->horizon < 1) return NULL;
+    if (cfg->task == DRONE_TASK_SWARM) {
+        const int A = cfg->agents_per_env;
+        if (A < 1 || A > 64 || (A & (A - 1)) || num_envs % A || cfg->env_offset % (uint32_t)A) return NULL;
+    }
     OracleVec* v = (OracleVec*)calloc(1, sizeof(OracleVec));
     v->envs = (Drone*)calloc((size_t)num_envs, sizeof(Drone));
     v->num_envs = num_envs;
@@ -97,7 +107,7 @@ OracleVec* oracle_vec_init(float* observations, float* actions, float* rewards, 
     v->truncations = truncations;
     for (int i = 0; i < num_envs; i++) {
         Drone* e = &v->envs[i];
-        e->observations = observations + (size_t)i * DRONE_OBS_DIM;
+        e->observations = observations + (size_t)i * (size_t)oracle_obs_dim(cfg->task);
         e->actions = actions + (size_t)i * DRONE_ACT_DIM;
         e->rewards = rewards + i;
         e->terminals = terminals + i;
@@ -117,13 +127,24 @@ void oracle_set_threads(OracleVec* v, int threads) { v->threads = threads < 1 ? 
 void oracle_vec_reset(OracleVec* v, uint64_t seed) {
     set_keys(v, seed);
     v->gstep = 0;
-    for (int i = 0; i < v->num_envs; i++) c_reset(&v->envs[i]);
+    if (v->cfg.task == DRONE_TASK_SWARM) {
+        const int A = v->cfg.agents_per_env;
+        for (int g = 0; g < v->num_envs / A; g++) c_reset_swarm(&v->envs[(size_t)g * A], A);
+    } else {
+        for (int i = 0; i < v->num_envs; i++) c_reset(&v->envs[i]);
+    }
 }
 
 void oracle_vec_step(OracleVec* v) {
     const int n = v->num_envs;
+    if (v->cfg.task == DRONE_TASK_SWARM) {
+        const int A = v->cfg.agents_per_env, groups = n / A;
 #pragma omp parallel for schedule(static) num_threads(v->threads) if (v->threads > 1)
-    for (int i = 0; i < n; i++) c_step(&v->envs[i]);
+        for (int g = 0; g < groups; g++) c_step_swarm(&v->envs[(size_t)g * A], A);
+    } else {
+#pragma omp parallel for schedule(static) num_threads(v->threads) if (v->threads > 1)
+        for (int i = 0; i < n; i++) c_step(&v->envs[i]);
+    }
     v->gstep += 1;
 }
 
@@ -248,10 +269,10 @@ uint32_t oracle_stream_key(uint64_t seed, uint32_t stream) { return stream_key(s
 uint32_t oracle_rng_draw(uint32_t key, uint32_t env, uint32_t ctr, uint32_t d) {
     return rng_draw(rng_base(key, env, ctr), d);
 }
-void oracle_params_derive(const DroneConfig* c, float* out27) {
+void oracle_params_derive(const DroneConfig* c, float* out30) {
     Params p;
     params_derive(c, &p);
-    memcpy(out27, &p, sizeof(Params));
+    memcpy(out30, &p, sizeof(Params));
 }
 int oracle_omp_max_threads(void) {
 #ifdef _OPENMP

@@ -86,7 +86,7 @@ def default_config(task=0, **overrides):
 
 
 def params(cfg):
-    out = np.zeros(27, dtype=np.float32)
+    out = np.zeros(30, dtype=np.float32)
     lib().oracle_params_derive(C.byref(cfg), out.ctypes.data)
     return out
 
@@ -99,7 +99,7 @@ class OracleVec:
         self.cfg = cfg if cfg is not None else default_config(task, **overrides)
         self.num_envs = int(num_envs)
         n = self.num_envs
-        self.observations = np.zeros((n, abi.OBS_DIM), dtype=np.float32)
+        self.observations = np.zeros((n, abi.obs_dim(self.cfg.task)), dtype=np.float32)
         self.actions = np.zeros((n, abi.ACT_DIM), dtype=np.float32)
         self.rewards = np.zeros(n, dtype=np.float32)
         self.terminals = np.zeros(n, dtype=np.uint8)

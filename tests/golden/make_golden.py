@@ -21,8 +21,8 @@ CHECKPOINTS = (1, 10, 100, 1000)
 N, SEED = 64, 20251017
 
 
-def run(task, horizon, env_offset):
-    cfg = pyoracle.default_config(task, horizon=horizon, env_offset=env_offset)
+def run(task, horizon, env_offset, **extra):
+    cfg = pyoracle.default_config(task, horizon=horizon, env_offset=env_offset, **extra)
     v = pyoracle.OracleVec(N, seed=SEED, cfg=cfg)
     v.reset(SEED)
     out = {"reset_state": v.get_state().copy(), "reset_obs": v.observations.copy()}
@@ -47,8 +47,9 @@ def run(task, horizon, env_offset):
 
 
 def main():
-    for name, task, horizon, off in (("hover", 0, 1024, 0), ("waypoint", 1, 1024, 0), ("hover_h100_off", 0, 100, 1 << 20)):
-        np.savez_compressed(os.path.join(HERE, f"golden_{name}.npz"), **run(task, horizon, off))
+    for name, task, horizon, off, extra in (("hover", 0, 1024, 0, {}), ("waypoint", 1, 1024, 0, {}), ("hover_h100_off", 0, 100, 1 << 20, {}),
+                                             ("swarm", 2, 300, 64, {"collision_radius": 0.5})):
+        np.savez_compressed(os.path.join(HERE, f"golden_{name}.npz"), **run(task, horizon, off, **extra))
         print("wrote", name)
 
 

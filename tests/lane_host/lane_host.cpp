@@ -3,6 +3,7 @@
 // oracle can be checked without a GPU. This object is never part of the
 // product library; libdrone_hip.so has no CPU path.
 #include <cstring>
+#include <vector>
 
 #include "../../drone_amd/csrc/drone_lane.hpp"
 
@@ -29,19 +30,40 @@ static void lane_to_row(const Lane& L, DroneStateRow& r) {
 
 extern "C" {
 
+// the swarm task's cross-lane exchange, done here by walking the lanes of the group
+static void group_neighbour(const KParams& P, const std::vector<Lane>& lanes, int i, float& nn_d2, float (&nn_e)[3]) {
+    const int A = (int)P.agents, base = i - (i % A);
+    nearest_neighbour(P, [&](uint32_t d, float (&e)[3]) {
+        const Lane& o = lanes[base + ((i - base + (int)d) % A)];
+        for (int c = 0; c < 3; c++) e[c] = o.s.p[c] - lanes[i].s.p[c];
+    }, nn_d2, nn_e);
+}
+
+static void write_obs(const DroneConfig* cfg, const KParams& P, const std::vector<Lane>& lanes, float* obs) {
+    const int od = cfg->task == DRONE_TASK_SWARM ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM;
+    for (size_t i = 0; i < lanes.size(); i++) {
+        float o[DRONE_OBS_DIM_MAX];
+        lane_obs(P, lanes[i], o);
+        if (cfg->task == DRONE_TASK_SWARM) {
+            float nn_d2, nn_e[3];
+            group_neighbour(P, lanes, (int)i, nn_d2, nn_e);
+            lane_obs_neighbour(P, lanes[i], nn_d2, nn_e, o);
+        }
+        memcpy(obs + i * od, o, sizeof(float) * od);
+    }
+}
+
 void lane_host_reset(const DroneConfig* cfg, uint64_t seed, DroneStateRow* rows, float* obs, int n) {
     KParams P;
     derive_kparams(*cfg, seed, P);
+    std::vector<Lane> lanes(n);
     for (int i = 0; i < n; i++) {
-        Lane L;
         memset(&rows[i], 0, sizeof(DroneStateRow));
-        L.episode = 0;
-        lane_reset(P, L, P.env_offset + (uint32_t)i);
-        lane_to_row(L, rows[i]);
-        float o[DRONE_OBS_DIM];
-        lane_obs(P, L, o);
-        memcpy(obs + (size_t)i * DRONE_OBS_DIM, o, sizeof(o));
+        lanes[i].episode = 0;
+        lane_reset(P, lanes[i], P.env_offset + (uint32_t)i);
+        lane_to_row(lanes[i], rows[i]);
     }
+    write_obs(cfg, P, lanes, obs);
 }
 
 // One vec step over AoS rows with the kernel's lane code. random_policy != 0:
@@ -50,9 +72,11 @@ void lane_host_step(const DroneConfig* cfg, uint64_t seed, uint32_t gstep, Drone
                     float* rew, unsigned char* term, unsigned char* trunc, int n, int random_policy) {
     KParams P;
     derive_kparams(*cfg, seed, P);
+    std::vector<Lane> lanes(n);
+    std::vector<StepCtx> ctx(n);
+    std::vector<StepOut> outs(n);
     for (int i = 0; i < n; i++) {
-        Lane L;
-        row_to_lane(rows[i], L);
+        row_to_lane(rows[i], lanes[i]);
         const uint32_t env = P.env_offset + (uint32_t)i;
         float act[4];
         if (random_policy) {
@@ -61,10 +85,21 @@ void lane_host_step(const DroneConfig* cfg, uint64_t seed, uint32_t gstep, Drone
         } else {
             memcpy(act, actions + (size_t)i * 4, 16);
         }
-        StepOut out;
-        if (cfg->task == DRONE_TASK_HOVER) lane_step<DRONE_TASK_HOVER>(P, L, act, env, gstep, out);
-        else lane_step<DRONE_TASK_WAYPOINT>(P, L, act, env, gstep, out);
-        lane_to_row(L, rows[i]);
+        if (cfg->task == DRONE_TASK_HOVER) lane_step<DRONE_TASK_HOVER>(P, lanes[i], act, env, gstep, outs[i]);
+        else if (cfg->task == DRONE_TASK_WAYPOINT) lane_step<DRONE_TASK_WAYPOINT>(P, lanes[i], act, env, gstep, outs[i]);
+        else lane_integrate<DRONE_TASK_SWARM>(P, lanes[i], act, env, gstep, ctx[i]);
+    }
+    if (cfg->task == DRONE_TASK_SWARM) {
+        std::vector<float> nn(n);
+        for (int i = 0; i < n; i++) {  // every agent has integrated: neighbours on post-integration positions
+            float e[3];
+            group_neighbour(P, lanes, i, nn[i], e);
+        }
+        for (int i = 0; i < n; i++) lane_finish<DRONE_TASK_SWARM>(P, lanes[i], P.env_offset + (uint32_t)i, ctx[i], nn[i], outs[i]);
+    }
+    for (int i = 0; i < n; i++) {
+        const StepOut& out = outs[i];
+        lane_to_row(lanes[i], rows[i]);
         if (out.oob || out.trunc) {
             rows[i].perf_sum += out.perf;
             rows[i].score_sum += out.score;
@@ -76,15 +111,13 @@ void lane_host_step(const DroneConfig* cfg, uint64_t seed, uint32_t gstep, Drone
         rew[i] = out.reward;
         term[i] = out.oob;
         trunc[i] = out.trunc;
-        float o[DRONE_OBS_DIM];
-        lane_obs(P, L, o);
-        memcpy(obs + (size_t)i * DRONE_OBS_DIM, o, sizeof(o));
     }
+    write_obs(cfg, P, lanes, obs);
 }
 
-void lane_host_kparams(const DroneConfig* cfg, uint64_t seed, uint32_t* out52) {
+void lane_host_kparams(const DroneConfig* cfg, uint64_t seed, uint32_t* out56) {
     KParams P;
     derive_kparams(*cfg, seed, P);
-    memcpy(out52, &P, sizeof(P));
+    memcpy(out56, &P, sizeof(P));
 }
 }

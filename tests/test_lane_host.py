@@ -29,14 +29,15 @@ def p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-@pytest.mark.parametrize("task,horizon,substeps", [(0, 1024, 1), (1, 1024, 1), (0, 37, 1), (1, 41, 2)])
+@pytest.mark.parametrize("task,horizon,substeps", [(0, 1024, 1), (1, 1024, 1), (0, 37, 1), (1, 41, 2), (2, 1024, 1), (2, 60, 2)])
 def test_lane_math_bit_exact_vs_oracle(lane, oracle, task, horizon, substeps):
     n, seed = 1024, 4242
-    cfg = oracle.default_config(task, horizon=horizon, substeps=substeps, env_offset=777)
+    extra = dict(collision_radius=0.6, agents_per_env=16, env_offset=784) if task == 2 else dict(env_offset=777)
+    cfg = oracle.default_config(task, horizon=horizon, substeps=substeps, **extra)
     v = oracle.OracleVec(n, seed=seed, cfg=cfg, threads=4)
     v.reset(seed)
     rows = np.zeros(n, dtype=abi.state_row_dtype())
-    obs = np.zeros((n, 20), np.float32)
+    obs = np.zeros((n, abi.obs_dim(task)), np.float32)
     act = np.zeros((n, 4), np.float32)
     rew = np.zeros(n, np.float32)
     term = np.zeros(n, np.uint8)
@@ -61,14 +62,14 @@ def test_lane_math_bit_exact_vs_oracle(lane, oracle, task, horizon, substeps):
 def test_kparams_match_oracle_params(lane, oracle):
     cfg = oracle.default_config(1, substeps=3, dt=0.02)
     want = oracle.params(cfg)
-    kp = np.zeros(52, np.uint32)
+    kp = np.zeros(56, np.uint32)
     lane.lane_host_kparams(C.byref(cfg), C.c_uint64(9), p(kp))
     f = kp.view(np.float32)
     # oracle Params order -> KParams word index
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27, 28, 35, 36]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27, 28, 35, 36, 43, 44, 45]
     assert_bits_equal(want, f[idx].copy(), "derived params")
     keys = [oracle.lib().oracle_stream_key(9, s) for s in range(4)]
-    assert list(kp[45:49]) == keys
+    assert list(kp[49:53]) == keys
 
 
 def test_random_configs_bit_exact(lane, oracle):
@@ -77,7 +78,7 @@ def test_random_configs_bit_exact(lane, oracle):
     rng = np.random.default_rng(123)
     n = 256
     for trial in range(20):
-        task = trial % 2
+        task = trial % 3
         over = dict(
             horizon=int(rng.integers(5, 120)), substeps=int(rng.integers(1, 4)), dt=float(rng.uniform(0.002, 0.03)),
             mass=float(rng.uniform(0.02, 1.5)), arm=float(rng.uniform(0.03, 0.3)),
@@ -91,13 +92,14 @@ def test_random_configs_bit_exact(lane, oracle):
             wind_theta=float(rng.uniform(0, 2)), wind_sigma=float(rng.uniform(0, 3)), wind_max=float(rng.uniform(1, 8)),
             c_omega=float(rng.uniform(0, 1e-3)), c_action=float(rng.uniform(0, 0.1)), crash_penalty=float(rng.uniform(0, 5)),
             progress_scale=float(rng.uniform(0.1, 3)), waypoint_bonus=float(rng.uniform(0, 3)),
-            env_offset=int(rng.integers(0, 2**31)))
+            env_offset=int(rng.integers(0, 2**25)) * 64, agents_per_env=int(2 ** rng.integers(0, 7)),
+            collision_radius=float(rng.uniform(0.05, 1.0)), proximity_radius=float(rng.uniform(0.3, 3.0)), c_proximity=float(rng.uniform(0, 2)))
         seed = int(rng.integers(0, 2**63))
         cfg = oracle.default_config(task, **over)
         v = oracle.OracleVec(n, seed=seed, cfg=cfg)
         v.reset(seed)
         rows = np.zeros(n, dtype=abi.state_row_dtype())
-        obs = np.zeros((n, 20), np.float32)
+        obs = np.zeros((n, abi.obs_dim(task)), np.float32)
         act = np.zeros((n, 4), np.float32)
         rew = np.zeros(n, np.float32)
         term = np.zeros(n, np.uint8)

@@ -90,11 +90,15 @@ def test_reset_known_answers(oracle):
     assert abs(st["rpm"][0, 0] - hover) / hover < 1e-6
 
 
-@pytest.mark.parametrize("name,task,horizon,off", [("hover", 0, 1024, 0), ("waypoint", 1, 1024, 0), ("hover_h100_off", 0, 100, 1 << 20)])
-def test_oracle_reproduces_golden_vectors(oracle, name, task, horizon, off):
+GOLDEN_CASES = [("hover", 0, 1024, 0, {}), ("waypoint", 1, 1024, 0, {}), ("hover_h100_off", 0, 100, 1 << 20, {}),
+                ("swarm", 2, 300, 64, {"collision_radius": 0.5})]
+
+
+@pytest.mark.parametrize("name,task,horizon,off,extra", GOLDEN_CASES)
+def test_oracle_reproduces_golden_vectors(oracle, name, task, horizon, off, extra):
     g = np.load(os.path.join(GOLD, f"golden_{name}.npz"))
     n, seed = 64, 20251017
-    v = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, horizon=horizon, env_offset=off), threads=2)
+    v = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, horizon=horizon, env_offset=off, **extra), threads=2)
     v.reset(seed)
     assert_state_equal(g["reset_state"], v.get_state(), "reset_state")
     assert_bits_equal(g["reset_obs"], v.observations, "reset_obs")
@@ -233,3 +237,54 @@ def test_rollout_outputs_definition(oracle):
     assert_bits_equal(a.truncations, anyt, "truncation any")
     assert_bits_equal(a.observations, b.observations, "final obs")
     assert a.gstep == b.gstep == T
+
+
+def test_swarm_collisions_are_mutual_and_neighbour_obs(oracle):
+    """SPEC.md §10: squared distances are bitwise symmetric, so collisions come in
+    pairs (or larger clusters); neighbour observations follow the definition."""
+    n, A = 512, 8
+    cfg = oracle.default_config(2, agents_per_env=A, collision_radius=0.7, horizon=10_000)
+    v = oracle.OracleVec(n, seed=3, cfg=cfg)
+    v.reset(3)
+    st = v.get_state()
+    pos = st["pos"].astype(np.float64).reshape(n // A, A, 3)
+    d = np.linalg.norm(pos[:, :, None, :] - pos[:, None, :, :], axis=-1) + np.eye(A) * 1e9
+    np.testing.assert_allclose(v.observations[:, 23].reshape(n // A, A), (d.min(-1) / 5.0) ** 2, rtol=1e-5)
+    collisions = 0
+    for t in range(150):
+        v.fill_random_actions()
+        before = v.get_state()["episode"].copy()
+        v.step()
+        st = v.get_state()
+        crashed = v.terminals.astype(bool).reshape(n // A, A)
+        for g in np.flatnonzero(crashed.any(1)):
+            # an agent that crashed without leaving the box must have a crashed partner in its swarm
+            collisions += int(crashed[g].sum() >= 2)
+        assert np.all((st["episode"] - before) == (v.terminals | v.truncations))
+    assert collisions > 0
+    assert np.isfinite(v.observations).all()
+
+
+def test_swarm_of_one_is_hover_plus_far_neighbour(oracle):
+    a = oracle.OracleVec(64, seed=5, cfg=oracle.default_config(2, agents_per_env=1, c_proximity=0.7))
+    b = oracle.OracleVec(64, seed=5, cfg=oracle.default_config(0))
+    a.reset(5)
+    b.reset(5)
+    for t in range(200):
+        a.fill_random_actions()
+        b.fill_random_actions()
+        a.step()
+        b.step()
+        assert_bits_equal(a.rewards, b.rewards, f"rewards {t}")  # proximity term is exactly zero beyond the range
+    assert_state_equal(a.get_state(), b.get_state(), "A=1 swarm == hover")
+    assert_bits_equal(a.observations[:, :20].copy(), b.observations, "first 20 obs")
+    assert np.all(a.observations[:, 20:23] == 0) and np.all(a.observations[:, 23] == np.float32(16.0))
+
+
+def test_swarm_rejects_bad_grouping(oracle):
+    with pytest.raises(RuntimeError):
+        oracle.OracleVec(100, cfg=oracle.default_config(2, agents_per_env=8))   # 100 % 8 != 0
+    with pytest.raises(RuntimeError):
+        oracle.OracleVec(64, cfg=oracle.default_config(2, agents_per_env=6))    # not a power of two
+    with pytest.raises(RuntimeError):
+        oracle.OracleVec(64, cfg=oracle.default_config(2, agents_per_env=8, env_offset=4))

@@ -364,3 +364,40 @@ def test_host_buffer_transports(oracle, hip, zero_copy, monkeypatch):
         h.step()
     assert_outputs_equal(o, h, "after rebinding")
     assert_state_equal(o.get_state(), h.get_state(), "host transport state")
+
+
+@pytest.mark.parametrize("agents,n,device", [(8, 4096, None), (64, 4096, None), (2, 3000, "cuda:0"), (1, 777, None), (16, 65536, "cuda:0")])
+def test_swarm_task_bit_exact(oracle, hip, agents, n, device):
+    """Task 2 (SPEC.md §10): agents coupled through a nearest-neighbour term found with
+    lane shuffles inside the wave; collisions forced to be frequent."""
+    over = dict(agents_per_env=agents, collision_radius=0.6, proximity_radius=1.5, horizon=90, env_offset=64 * 5)
+    o, h = make_pair(oracle, hip, n, 606, 2, device=device, **over)
+    assert to_np(h.observations).shape == (n, 24)
+    assert_outputs_equal(o, h, "swarm reset")
+    crashes = 0
+    for t in range(250):
+        o.fill_random_actions()
+        if device is None:
+            set_actions(h, o.actions)
+        else:
+            h.fill_random_actions()
+        o.step()
+        h.step()
+        if t % 10 == 0 or t > 240:
+            assert_outputs_equal(o, h, f"swarm step {t}")
+        crashes += int(o.terminals.sum())
+    assert_state_equal(o.get_state(), h.get_state(), "swarm state")
+    assert crashes > 0
+    o.rollout(60)
+    h.rollout(60)
+    assert_outputs_equal(o, h, "swarm fused rollout")
+    assert_state_equal(o.get_state(), h.get_state(), "swarm state after fused rollout")
+    lo, lh = o.log(), h.log()
+    assert lo["n"] == lh["n"] > 0
+
+
+def test_swarm_rejects_bad_grouping(hip):
+    with pytest.raises(RuntimeError, match="multiples of agents_per_env"):
+        hip.DroneVec(100, cfg=hip.default_config(2, agents_per_env=8))
+    with pytest.raises(RuntimeError, match="power of two"):
+        hip.DroneVec(96, cfg=hip.default_config(2, agents_per_env=6))
