@@ -119,6 +119,7 @@ bool validate(const DroneConfig* c, int num_envs) {
         set_err("physical constants must be positive");
         return false;
     }
+    if (c->task == DRONE_TASK_WAYPOINT && !(c->wind_max > 0.0f)) { set_err("wind_max must be positive (SPEC.md §4: clamp bounds are never zero)"); return false; }
     return true;
 }
 

@@ -88,6 +88,7 @@ OracleVec* oracle_vec_init(float* observations, float* actions, float* rewards, 
                            unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {
     if (!cfg || cfg->struct_size != sizeof(DroneConfig) || num_envs <= 0) return NULL;
     if (cfg->substeps < 1 || cfg->horizon < 1) return NULL;
+    if (cfg->task == DRONE_TASK_WAYPOINT && !(cfg->wind_max > 0.0f)) return NULL; /* clamp bounds are never zero (SPEC.md §4) */
     if (cfg->task == DRONE_TASK_SWARM) {
         const int A = cfg->agents_per_env;
         if (A < 1 || A > 64 || (A & (A - 1)) || num_envs % A || cfg->env_offset % (uint32_t)A) return NULL;
