@@ -402,6 +402,7 @@ void drone_vec_close(DroneVec* v) {
 
 int drone_vec_set_stream(DroneVec* v, void* hip_stream) {
     if (!v) return -1;
+    if ((hipStream_t)hip_stream == v->stream && !v->own_stream) return 0;  // cheap to call every step
     if (!set_device(v)) return -1;
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     if (v->own_stream && v->stream) (void)hipStreamDestroy(v->stream);

@@ -57,6 +57,8 @@ class Drone:
                 self.vec.actions[:] = actions
             else:
                 self.vec.actions.copy_(actions, non_blocking=True)
+        if self.vec.torch_device is not None:
+            self.vec.use_torch_stream()  # follow torch.cuda.stream(...) contexts; a no-op while the stream is unchanged
         self.vec.step()
         self.tick += 1
         infos = []
