@@ -58,7 +58,6 @@ def test_random_policy_known_answers(oracle):
         a = v.fill_random_actions(gstep=g)
         for i in (0, 1, 100, 256):
             h0, h1 = py_draw(key, off + i, g, 0), py_draw(key, off + i, g, 1)
-            want = [((h & 0xFFFF) - 32768) / 32768.0 for h in (h0, h0 >> 16 << 0)]  # placeholder, replaced below
             want = [((h0 & 0xFFFF) - 32768) / 32768.0, ((h0 >> 16) - 32768) / 32768.0,
                     ((h1 & 0xFFFF) - 32768) / 32768.0, ((h1 >> 16) - 32768) / 32768.0]
             assert a[i].tolist() == want
@@ -77,8 +76,8 @@ def test_reset_known_answers(oracle):
     f32 = np.float32
     for i in range(8):
         u = [py_draw(key, off + i, 0, d) for d in range(9)]
-        sym = [f32(np.fma(f32(2.0), f32(x >> 8) * f32(2.0**-24), f32(-1.0))) if hasattr(np, "fma") else f32(f32(2.0) * (f32(x >> 8) * f32(2.0**-24)) - f32(1.0)) for x in u]
-        # 2*u01 is exact in float32 (power-of-two scale), so fma and mul+add agree here
+        # 2*u01 - 1 is exact in float32 (24-bit u01, power-of-two scale), so fma and mul+add agree
+        sym = [f32(f32(2.0) * (f32(x >> 8) * f32(2.0**-24)) - f32(1.0)) for x in u]
         assert st["pos"][i].tolist() == [float(f32(cfg.spawn_extent) * s) for s in sym[0:3]]
         assert st["target"][i].tolist() == [float(f32(cfg.target_extent) * s) for s in sym[3:6]]
         t = [f32(cfg.tilt_init) * s for s in sym[6:9]]
