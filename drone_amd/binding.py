@@ -83,14 +83,27 @@ class DroneVec:
     stream for that device.
     """
 
-    def __init__(self, num_envs, seed=0, task=abi.TASK_HOVER, device=None, cfg=None, fns=None, **overrides):
+    def __init__(self, num_envs, seed=0, task=abi.TASK_HOVER, device=None, cfg=None, fns=None, buffers=None, **overrides):
         load()
         self._f = _fns if fns is None else fns
         self.num_envs = int(num_envs)
         n = self.num_envs
         self.cfg = cfg if cfg is not None else default_config(task, **overrides)
         self._h = None
-        if device is None:
+        if buffers is not None:
+            # caller-owned buffers (the PufferLib contract: the vec-env allocates them, possibly as
+            # slices of one shared-memory block, and every env writes into its slice)
+            obs, act, rew, term, trunc = buffers
+            self._check_buffers(obs, act, rew, term, trunc, n, abi.obs_dim(self.cfg.task))
+            self.observations, self.actions, self.rewards, self.terminals, self.truncations = obs, act, rew, term, trunc
+            if _is_torch(obs):
+                self.torch_device = obs.device
+                self.cfg.buffer_kind = abi.BUFFERS_DEVICE
+                self.cfg.device = obs.device.index if obs.device.index is not None else 0
+            else:
+                self.torch_device = None
+                self.cfg.buffer_kind = abi.BUFFERS_HOST
+        elif device is None:
             self.torch_device = None
             self.cfg.buffer_kind = abi.BUFFERS_HOST
             self.observations = np.zeros((n, abi.obs_dim(self.cfg.task)), dtype=np.float32)
@@ -119,6 +132,24 @@ class DroneVec:
             raise RuntimeError("drone_vec_init failed: " + self._f["drone_last_error"]().decode())
         if self.torch_device is not None:
             self.use_torch_stream()
+
+    @staticmethod
+    def _check_buffers(obs, act, rew, term, trunc, n, obs_dim):
+        want = ((obs, (n, obs_dim), "float32"), (act, (n, abi.ACT_DIM), "float32"), (rew, (n,), "float32"),
+                (term, (n,), "uint8"), (trunc, (n,), "uint8"))
+        kinds = {_is_torch(b) for b, _, _ in want}
+        if len(kinds) != 1:
+            raise TypeError("buffers must be all numpy arrays or all torch tensors")
+        for b, shape, dt in want:
+            if tuple(b.shape) != shape:
+                raise ValueError(f"buffer shape {tuple(b.shape)} != {shape}")
+            if str(b.dtype).replace("torch.", "") not in (dt, "bool" if dt == "uint8" else dt):
+                raise TypeError(f"buffer dtype {b.dtype} != {dt}")
+            contiguous = b.is_contiguous() if _is_torch(b) else b.flags["C_CONTIGUOUS"]
+            if not contiguous:
+                raise ValueError("buffers must be C-contiguous")
+            if _is_torch(b) and b.device.type != "cuda":
+                raise ValueError("torch buffers must live on a GPU (pass numpy arrays for host buffers)")
 
     # -- stream plumbing --
     def use_torch_stream(self):

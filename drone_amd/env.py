@@ -27,9 +27,14 @@ class Box:
 
 
 class Drone:
-    def __init__(self, num_envs=1024, task="hover", device=None, seed=0, log_interval=128, **config):
+    def __init__(self, num_envs=1024, task="hover", device=None, seed=0, log_interval=128, buf=None, **config):
+        """``buf``: PufferLib-style buffer holder — any object with ``observations``,
+        ``actions``, ``rewards``, ``terminals``, ``truncations`` arrays (numpy for the host
+        path, torch CUDA tensors for the device path), e.g. a worker's slice of the
+        vec-env's shared memory. Without it the env allocates its own."""
         task_id = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT, "swarm": abi.TASK_SWARM}[task] if isinstance(task, str) else int(task)
-        self.vec = binding.DroneVec(num_envs, seed=seed, task=task_id, device=device, **config)
+        buffers = None if buf is None else (buf.observations, buf.actions, buf.rewards, buf.terminals, buf.truncations)
+        self.vec = binding.DroneVec(num_envs, seed=seed, task=task_id, device=device, buffers=buffers, **config)
         self.num_agents = self.vec.num_envs
         self.single_observation_space = Box(-np.inf, np.inf, (abi.obs_dim(task_id),))
         self.single_action_space = Box(-1.0, 1.0, (abi.ACT_DIM,))

@@ -48,3 +48,52 @@ def test_env_class_matches_oracle_and_reports_logs(oracle, hip, device):
     total_n = sum(l["n"] for l in got_log)
     assert total_n == o.log()["n"]
     env.close()
+
+
+@pytest.mark.gpu
+def test_env_class_on_slices_of_a_shared_block(oracle, hip):
+    """The PufferLib vec-env contract: the caller allocates ONE block per buffer kind and
+    hands every env (worker) a slice of it; two envs here fill one block between them."""
+    from types import SimpleNamespace
+
+    from drone_amd.env import Drone
+    from helpers import assert_bits_equal
+
+    n, seed = 300, 8  # per env; 300 * 80 B keeps the second slice 16-B aligned
+    block = SimpleNamespace(observations=np.zeros((2 * n, 20), np.float32), actions=np.zeros((2 * n, 4), np.float32),
+                            rewards=np.zeros(2 * n, np.float32), terminals=np.zeros(2 * n, np.uint8), truncations=np.zeros(2 * n, np.uint8))
+    envs = []
+    for w in range(2):
+        sl = slice(w * n, (w + 1) * n)
+        buf = SimpleNamespace(**{k: getattr(block, k)[sl] for k in vars(block)})
+        envs.append(Drone(num_envs=n, task="hover", seed=seed, log_interval=0, buf=buf, env_offset=w * n, horizon=35))
+    o = oracle.OracleVec(2 * n, seed=seed, cfg=oracle.default_config(0, horizon=35))
+    o.reset(seed)
+    for e in envs:
+        e.reset(seed)
+    assert_bits_equal(o.observations, block.observations, "reset obs in the shared block")
+    for t in range(80):
+        o.fill_random_actions()
+        block.actions[:] = o.actions          # the "policy" writes the shared action block
+        o.step()
+        for e in envs:
+            e.step(e.actions)                 # each env steps on its own slice, in place
+    assert_bits_equal(o.observations, block.observations, "obs")
+    assert_bits_equal(o.rewards, block.rewards, "rewards")
+    assert_bits_equal(o.terminals, block.terminals, "terminals")
+    assert_bits_equal(o.truncations, block.truncations, "truncations")
+    for e in envs:
+        e.close()
+
+
+def test_buffer_validation(hip):
+    from drone_amd.binding import DroneVec
+
+    n = 16
+    good = (np.zeros((n, 20), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+    bad_shape = (np.zeros((n, 19), np.float32),) + good[1:]
+    bad_dtype = (good[0], np.zeros((n, 4), np.float64)) + good[2:]
+    strided = (np.zeros((n, 40), np.float32)[:, ::2],) + good[1:]
+    for bufs, exc in ((bad_shape, ValueError), (bad_dtype, TypeError), (strided, ValueError)):
+        with pytest.raises(exc):
+            DroneVec(n, buffers=bufs)
