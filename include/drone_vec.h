@@ -140,7 +140,8 @@ int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count);
 int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int count);
 
 /* compact_done=1 only: ids (local) of the envs that finished in the last
- * step, unordered; returns their count (or -1). Copies at most `cap` ids. */
+ * drone_vec_step (not drone_vec_rollout, which does not build the list),
+ * unordered; returns their count (or -1). Copies at most `cap` ids. */
 int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap);
 
 /* HIP-event timer on the handle's stream: start, ..launches.., stop → ms. */
