@@ -107,7 +107,12 @@ static inline uint32_t rng_draw(uint32_t base, uint32_t d) { return hash32(base 
 static inline float u01(uint32_t u) { return (float)(u >> 8) * 5.9604645e-8f; }
 static inline float sym(uint32_t u) { return fmaf(2.0f, u01(u), -1.0f); }
 static inline float s16(uint32_t h) { return (float)((int)h - 32768) * 3.0517578125e-5f; }
-static inline float clampc(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+/* C99 fmaxf / fminf semantics for the operands the spec feeds them (a NaN operand
+ * yields the other one; no signalling NaNs, no zero-vs-zero ties), written out so
+ * that the compiler inlines compare + select instead of calling libm. */
+static inline float fmax_(float a, float b) { return (a >= b || b != b) ? a : b; }
+static inline float fmin_(float a, float b) { return (a <= b || b != b) ? a : b; }
+static inline float clampc(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 
 static inline void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float a[4]) {
     uint32_t b = rng_base(key_action, env, gstep);
@@ -332,7 +337,7 @@ static inline void step_integrate(Drone* env) {
         for (int i = 0; i < 4; i++) q[i] = q[i] * sc;
         for (int i = 0; i < 3; i++) s->vel[i] = clampc(s->vel[i], -c->max_vel, c->max_vel);
         for (int i = 0; i < 3; i++) s->omega[i] = clampc(s->omega[i], -c->max_omega, c->max_omega);
-        for (int i = 0; i < 4; i++) s->rpm[i] = fminf(s->rpm[i] < 0.0f ? 0.0f : s->rpm[i], c->max_rpm);
+        for (int i = 0; i < 4; i++) s->rpm[i] = fmin_(s->rpm[i] < 0.0f ? 0.0f : s->rpm[i], c->max_rpm);
     }
     env->tick += 1;
 }
@@ -374,7 +379,7 @@ static inline void step_finish(Drone* env, float nn_d2) {
     if (c->task != DRONE_TASK_WAYPOINT) {
         r = fmaf(-p->half_inv_bound, dist, 1.0f) - pen;
         if (dist < c->hover_radius) env->score_count += 1;
-        if (c->task == DRONE_TASK_SWARM) r = r - c->c_proximity * fmaxf(0.0f, fmaf(-nn_d2, p->inv_prox_r2, 1.0f));
+        if (c->task == DRONE_TASK_SWARM) r = r - c->c_proximity * fmax_(0.0f, fmaf(-nn_d2, p->inv_prox_r2, 1.0f));
     } else {
         r = c->progress_scale * (env->scratch_prev_dist - dist) - pen;
         if (!oob && dist < c->waypoint_radius) {
