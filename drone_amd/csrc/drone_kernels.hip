@@ -212,26 +212,37 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
 }
 
 // SPEC.md §10: nearest neighbour among the lanes of this drone's swarm — the
-// A = P.agents consecutive lanes starting at lane & ~(A-1). One ds_bpermute per
-// coordinate and neighbour; every lane of the wave takes part (no divergence).
-__device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L, float& nn_d2, float (&nn_e)[3]) {
+// A = P.agents consecutive lanes starting at lane & ~(A-1). Each lane parks its
+// position as one float4 in the wave's (otherwise idle) observation tile and
+// reads its neighbours back with one ds_read_b128 each — a third of the LDS
+// operations of three __shfl (ds_bpermute) per neighbour, which is what a swarm
+// of 64 is bound by (tools/swarm_scan.py: 85 -> 65 us per step at A = 64). The
+// tile is private to the wave and a wave's DS operations execute in order, so
+// wave-scope fences (compiler ordering only) are all the synchronisation needed.
+__device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L, float4* tile, float& nn_d2, float (&nn_e)[3]) {
     const uint32_t lane = threadIdx.x & (kWave - 1), mask = P.agents - 1u, base = lane & ~mask;
+    tile[lane] = make_float4(L.s.p[0], L.s.p[1], L.s.p[2], 0.0f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     nearest_neighbour(P, [&](uint32_t d, float (&e)[3]) {
-        const int src = (int)(base | ((lane + d) & mask));
-        e[0] = __shfl(L.s.p[0], src) - L.s.p[0];
-        e[1] = __shfl(L.s.p[1], src) - L.s.p[1];
-        e[2] = __shfl(L.s.p[2], src) - L.s.p[2];
+        const float4 q = tile[base | ((lane + d) & mask)];
+        e[0] = q.x - L.s.p[0];
+        e[1] = q.y - L.s.p[1];
+        e[2] = q.z - L.s.p[2];
     }, nn_d2, nn_e);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads are done before the tile is written again
+    __builtin_amdgcn_wave_barrier();
 }
 
 // steps 1-9 of one env step for any task (the swarm task looks at its neighbours in between)
 template <int TASK>
-__device__ __forceinline__ void step_any(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
+__device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     if (TASK == DRONE_TASK_SWARM) {
         StepCtx ctx;
         lane_integrate<TASK>(P, L, act, env, gstep, ctx);
         float nn_d2, nn_e[3];
-        swarm_neighbour(P, L, nn_d2, nn_e);
+        swarm_neighbour(P, L, tile, nn_d2, nn_e);
         lane_finish<TASK>(P, L, env, ctx, nn_d2, out);
     } else {
         lane_step<TASK>(P, L, act, env, gstep, out);
@@ -240,11 +251,11 @@ __device__ __forceinline__ void step_any(const KParams& P, Lane& L, const float 
 
 // the observation row of the (possibly fresh) state
 template <int TASK>
-__device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM_MAX]) {
+__device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float4* tile, float (&o)[DRONE_OBS_DIM_MAX]) {
     lane_obs(P, L, o);
     if (TASK == DRONE_TASK_SWARM) {
         float nn_d2, nn_e[3];
-        swarm_neighbour(P, L, nn_d2, nn_e);  // on the positions after resets
+        swarm_neighbour(P, L, tile, nn_d2, nn_e);  // on the positions after resets
         lane_obs_neighbour(P, L, nn_d2, nn_e, o);
     }
 }
@@ -295,7 +306,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         act[0] = av.x; act[1] = av.y; act[2] = av.z; act[3] = av.w;
     }
     StepOut out;
-    step_any<TASK>(P, L, act, P.env_offset + i, a.gstep, out);
+    step_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, P.env_offset + i, a.gstep, out);
     const bool done = valid && (out.oob || out.trunc);
 
     if (valid) {
@@ -324,7 +335,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     }
 
     float o[DRONE_OBS_DIM_MAX];
-    obs_any<TASK>(P, L, o);
+    obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
     write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base);
 }
 
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     if (i < n) a.v.rew[i] = 0.0f;
     if (a.v.done_count && i < 2) a.v.done_count[i] = 0u;
     float o[DRONE_OBS_DIM_MAX];
-    obs_any<TASK>(P, L, o);
+    obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
     write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, false, false, i, block_base);
 }
 
@@ -385,7 +396,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, a.gstep + t, act);
         StepOut out;
-        step_any<TASK>(P, L, act, env, a.gstep + t, out);
+        step_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, a.gstep + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -401,7 +412,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         }
     }
     float o[DRONE_OBS_DIM_MAX];
-    obs_any<TASK>(P, L, o);
+    obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
     write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, any_term, any_trunc, i, block_base);
 }
 
