@@ -401,3 +401,43 @@ def test_swarm_rejects_bad_grouping(hip):
         hip.DroneVec(100, cfg=hip.default_config(2, agents_per_env=8))
     with pytest.raises(RuntimeError, match="power of two"):
         hip.DroneVec(96, cfg=hip.default_config(2, agents_per_env=6))
+
+
+def test_random_configs_random_sizes(oracle, hip):
+    """Thirty random physical configurations x random shard sizes x the three tasks,
+    per-step and fused, through the C-ABI."""
+    rng = np.random.default_rng(2025)
+    for trial in range(30):
+        task = trial % 3
+        A = int(2 ** rng.integers(0, 7)) if task == 2 else 1
+        n = int(rng.integers(1, 40)) * A * int(rng.integers(1, 30))
+        over = dict(
+            horizon=int(rng.integers(5, 150)), substeps=int(rng.integers(1, 4)), dt=float(rng.uniform(0.002, 0.03)),
+            mass=float(rng.uniform(0.02, 1.5)), arm=float(rng.uniform(0.03, 0.3)),
+            ixx=float(rng.uniform(1e-5, 1e-2)), iyy=float(rng.uniform(1e-5, 1e-2)), izz=float(rng.uniform(2e-5, 2e-2)),
+            k_thrust=float(rng.uniform(1e-10, 1e-7)), k_torque=float(rng.uniform(1e-12, 1e-9)),
+            k_drag=float(rng.uniform(0, 0.05)), k_ang_damp=float(rng.uniform(0, 1e-4)), gravity=float(rng.uniform(1.6, 12)),
+            max_rpm=float(rng.uniform(5000, 30000)), motor_tau=float(rng.uniform(0.01, 0.2)),
+            max_vel=float(rng.uniform(5, 40)), max_omega=float(rng.uniform(10, 80)), bound=float(rng.uniform(2, 20)),
+            spawn_extent=float(rng.uniform(0.5, 2)), target_extent=float(rng.uniform(0.5, 2)), tilt_init=float(rng.uniform(0, 0.5)),
+            hover_radius=float(rng.uniform(0.1, 2)), waypoint_radius=float(rng.uniform(0.1, 3)),
+            wind_theta=float(rng.uniform(0, 2)), wind_sigma=float(rng.uniform(0, 3)), wind_max=float(rng.uniform(1, 8)),
+            c_omega=float(rng.uniform(0, 1e-3)), c_action=float(rng.uniform(0, 0.1)), crash_penalty=float(rng.uniform(0, 5)),
+            progress_scale=float(rng.uniform(0.1, 3)), waypoint_bonus=float(rng.uniform(0, 3)),
+            agents_per_env=A, collision_radius=float(rng.uniform(0.05, 1.0)), proximity_radius=float(rng.uniform(0.3, 3.0)),
+            c_proximity=float(rng.uniform(0, 2)), env_offset=int(rng.integers(0, 2**24)) * 64,
+            compact_done=int(rng.integers(0, 2)))
+        seed = int(rng.integers(0, 2**63))
+        o, h = make_pair(oracle, hip, n, seed, task, **over)
+        for t in range(60):
+            o.fill_random_actions()
+            set_actions(h, o.actions)
+            o.step()
+            h.step()
+        assert_outputs_equal(o, h, f"trial {trial} (task {task}, n {n}, A {A})")
+        o.rollout(25)
+        h.rollout(25)
+        assert_outputs_equal(o, h, f"trial {trial} fused")
+        assert_state_equal(o.get_state(), h.get_state(), f"trial {trial} state")
+        h.close()
+        o.close()
