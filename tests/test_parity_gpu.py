@@ -406,8 +406,10 @@ def test_swarm_rejects_bad_grouping(hip):
 def test_random_configs_random_sizes(oracle, hip):
     """Thirty random physical configurations x random shard sizes x the three tasks,
     per-step and fused, through the C-ABI."""
-    rng = np.random.default_rng(2025)
-    for trial in range(30):
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("DRONE_FUZZ_SEED", "2025")))
+    for trial in range(int(os.environ.get("DRONE_FUZZ_TRIALS", "30"))):
         task = trial % 3
         A = int(2 ** rng.integers(0, 7)) if task == 2 else 1
         n = int(rng.integers(1, 40)) * A * int(rng.integers(1, 30))
