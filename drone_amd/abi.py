@@ -13,10 +13,11 @@ ACT_DIM = 4
 TASK_HOVER = 0
 TASK_WAYPOINT = 1
 TASK_SWARM = 2
+TASK_RACE = 3
 
 
 def obs_dim(task):
-    return OBS_DIM_MAX if task == TASK_SWARM else OBS_DIM
+    return OBS_DIM_MAX if task in (TASK_SWARM, TASK_RACE) else OBS_DIM
 
 BUFFERS_HOST = 0
 BUFFERS_DEVICE = 1
@@ -44,6 +45,7 @@ class DroneConfig(C.Structure):
         ("wind_theta", _F), ("wind_sigma", _F), ("wind_max", _F),
         ("c_omega", _F), ("c_action", _F), ("crash_penalty", _F), ("progress_scale", _F), ("waypoint_bonus", _F),
         ("collision_radius", _F), ("proximity_radius", _F), ("c_proximity", _F),
+        ("gate_radius", _F),
     ]
 
     def as_dict(self):

@@ -57,7 +57,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kObsVecMax = DRONE_OBS_DIM_MAX / 4;  // float4 per observation row: 5 (tasks 0, 1) or 6 (swarm)
-template <int TASK> constexpr int obs_vec() { return TASK == DRONE_TASK_SWARM ? 6 : 5; }
+template <int TASK> constexpr int obs_vec() { return (TASK == DRONE_TASK_SWARM || TASK == DRONE_TASK_RACE) ? 6 : 5; }
+template <int TASK> constexpr bool has_aux_plane() { return TASK == DRONE_TASK_WAYPOINT || TASK == DRONE_TASK_RACE; }  // wind / gate normal
 constexpr int kFlagLanes = kBlock / 16;        // lanes that write one flag array of a workgroup, 16 B each
 static_assert(kBlock % kWave == 0 && 2 * kFlagLanes <= kWave, "workgroup must be 64..512 threads");
 
@@ -106,7 +107,7 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
     L.s.o[2] = d.x; L.s.r[0] = d.y; L.s.r[1] = d.z; L.s.r[2] = d.w;
     L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
     L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
-    if (TASK == DRONE_TASK_WAYPOINT) {
+    if (has_aux_plane<TASK>()) {
         const float4 w = pl[kPW * np + i];
         L.wind[0] = w.x; L.wind[1] = w.y; L.wind[2] = w.z;
     } else {
@@ -122,7 +123,8 @@ __device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np,
     pl[kP3 * np + i] = make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]);
     pl[kP4 * np + i] = make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count));
     if (target_changed) pl[kPT * np + i] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
-    if (TASK == DRONE_TASK_WAYPOINT) pl[kPW * np + i] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
+    // wind changes every step; a gate normal only together with its centre
+    if (TASK == DRONE_TASK_WAYPOINT || (TASK == DRONE_TASK_RACE && target_changed)) pl[kPW * np + i] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
 }
 
 // per-env log sums: touched only when an episode ended
@@ -253,6 +255,7 @@ __device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile
 template <int TASK>
 __device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float4* tile, float (&o)[DRONE_OBS_DIM_MAX]) {
     lane_obs(P, L, o);
+    if (TASK == DRONE_TASK_RACE) lane_obs_gate(P, L, o);
     if (TASK == DRONE_TASK_SWARM) {
         float nn_d2, nn_e[3];
         swarm_neighbour(P, L, tile, nn_d2, nn_e);  // on the positions after resets
@@ -351,8 +354,8 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     const uint32_t i = block_base + threadIdx.x;
     Lane L;
     L.episode = 0u;
-    lane_reset(P, L, P.env_offset + i);
-    store_lane<DRONE_TASK_WAYPOINT>(a.v.planes, np, i, L, true);  // every plane, wind included
+    lane_reset<TASK>(P, L, P.env_offset + i);
+    store_lane<DRONE_TASK_WAYPOINT>(a.v.planes, np, i, L, true);  // every plane, the aux plane (wind / gate normal) included
     a.v.planes[kL0 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.v.planes[kL1 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) a.v.rew[i] = 0.0f;
@@ -483,6 +486,7 @@ inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
     const dim3 g(v.n_pad / kBlock), b(kBlock);
     if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(make_args(v, 0));
+    else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(make_args(v, 0));
     else drone_reset_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(make_args(v, 0));
     return hipGetLastError();
 }
@@ -497,6 +501,9 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_
     } else if (task == DRONE_TASK_SWARM) {
         if (compact) drone_step_kernel<DRONE_TASK_SWARM, true><<<g, b, 0, s>>>(a);
         else drone_step_kernel<DRONE_TASK_SWARM, false><<<g, b, 0, s>>>(a);
+    } else if (task == DRONE_TASK_RACE) {
+        if (compact) drone_step_kernel<DRONE_TASK_RACE, true><<<g, b, 0, s>>>(a);
+        else drone_step_kernel<DRONE_TASK_RACE, false><<<g, b, 0, s>>>(a);
     } else {
         if (compact) drone_step_kernel<DRONE_TASK_WAYPOINT, true><<<g, b, 0, s>>>(a);
         else drone_step_kernel<DRONE_TASK_WAYPOINT, false><<<g, b, 0, s>>>(a);
@@ -509,6 +516,7 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     const dim3 g(grid_for(v.n)), b(kBlock);
     if (task == DRONE_TASK_HOVER) drone_rollout_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(a, horizon);
     else if (task == DRONE_TASK_SWARM) drone_rollout_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(a, horizon);
+    else if (task == DRONE_TASK_RACE) drone_rollout_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(a, horizon);
     else drone_rollout_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(a, horizon);
     return hipGetLastError();
 }

@@ -25,7 +25,7 @@ struct Dyn {
 struct Lane {
     Dyn s;
     float tgt[3];
-    float wind[3];
+    float wind[3];  // task 1: wind; task 3: unit normal of the current gate (the dynamics see no wind there)
     float ep_return;
     uint32_t tick, episode, score_count;
 };
@@ -39,6 +39,15 @@ struct StepOut {
 };
 
 DRONE_FN float clampc(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+
+DRONE_FN float dot3(const float (&a)[3], const float (&b)[3]) { return fma_(a[0], b[0], fma_(a[1], b[1], a[2] * b[2])); }
+
+// SPEC.md §11: unit(e)
+DRONE_FN void unit3(const float (&e)[3], float (&out)[3]) {
+    const float inv = 1.0f / sqrtf(dot3(e, e) + 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[i] = e[i] * inv;
+}
 
 // SPEC.md §4. ct[i] = cmd_i * inv_tau; 56 operations (59 with wind).
 template <int TASK>
@@ -110,6 +119,7 @@ DRONE_FN float target_dist(const Lane& L) {
 }
 
 // SPEC.md §6. `env` is the global env id.
+template <int TASK = DRONE_TASK_HOVER>
 DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     const uint32_t b = rng_base(P.key_reset, env, L.episode);
     float t[3];
@@ -136,6 +146,10 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     L.tick = 0;
     L.score_count = 0;
     L.ep_return = 0.0f;
+    if (TASK == DRONE_TASK_RACE) {  // SPEC.md §11: gate 0 faces the spawn point
+        const float e[3] = {L.tgt[0] - L.s.p[0], L.tgt[1] - L.s.p[1], L.tgt[2] - L.s.p[2]};
+        unit3(e, L.wind);
+    }
 }
 
 // SPEC.md §2: the synthetic random policy.
@@ -151,7 +165,8 @@ DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, f
 // What lane_integrate hands to lane_finish.
 struct StepCtx {
     float a2;         // |clamped action|^2
-    float prev_dist;  // waypoint task: distance before integrating
+    float prev_dist;  // waypoint / race tasks: distance before integrating
+    float p0[3];      // race task: position before integrating
 };
 
 // SPEC.md §5 steps 1–4: actions, wind, RK4, renormalise, clamp, tick.
@@ -174,6 +189,11 @@ DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], u
             const float xi = (float)((int)sum - 510);
             L.wind[i] = clampc(fma_(P.wind_decay, L.wind[i], P.wind_gain * xi), -P.wind_max, P.wind_max);
         }
+        ctx.prev_dist = target_dist(L);
+    }
+    if (TASK == DRONE_TASK_RACE) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) ctx.p0[i] = L.s.p[i];
         ctx.prev_dist = target_dist(L);
     }
 
@@ -228,7 +248,33 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
     const float pen = fma_(P.c_omega, w2, P.c_action * ctx.a2);
     float r;
     bool target_changed = false;
-    if (TASK != DRONE_TASK_WAYPOINT) {
+    if (TASK == DRONE_TASK_RACE) {
+        r = P.progress_scale * (ctx.prev_dist - dist) - pen;
+        const float d0[3] = {ctx.p0[0] - L.tgt[0], ctx.p0[1] - L.tgt[1], ctx.p0[2] - L.tgt[2]};
+        const float d1[3] = {L.s.p[0] - L.tgt[0], L.s.p[1] - L.tgt[1], L.s.p[2] - L.tgt[2]};
+        const float s0 = dot3(L.wind, d0), s1 = dot3(L.wind, d1);
+        if (!oob && s0 < 0.0f && s1 >= 0.0f) {  // crossed the gate plane forwards
+            const float t = s0 / (s0 - s1);
+            float m[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) m[i] = fma_(t, L.s.p[i] - ctx.p0[i], ctx.p0[i]) - L.tgt[i];
+            if (dot3(m, m) < P.gate_r2) {  // through the ring
+                r += P.waypoint_bonus;
+                L.score_count += 1u;
+                const uint32_t b = rng_base(P.key_waypoint, env, L.episode);
+                float cn[3], e[3];
+#pragma unroll
+                for (uint32_t i = 0; i < 3; i++) {
+                    cn[i] = P.target_extent * sym(rng_draw(b, 3u * L.score_count + i));
+                    e[i] = cn[i] - L.tgt[i];
+                }
+                unit3(e, L.wind);
+#pragma unroll
+                for (int i = 0; i < 3; i++) L.tgt[i] = cn[i];
+                target_changed = true;
+            }
+        }
+    } else if (TASK != DRONE_TASK_WAYPOINT) {
         r = fma_(-P.half_inv_bound, dist, 1.0f) - pen;
         if (dist < P.hover_radius) L.score_count += 1u;
         if (TASK == DRONE_TASK_SWARM) r = r - P.c_proximity * __builtin_fmaxf(0.0f, fma_(-nn_d2, P.inv_prox_r2, 1.0f));
@@ -252,7 +298,7 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
     out.perf = out.score = out.ep_return = out.ep_len = 0.0f;
     if (oob || trunc) {
         float score, perf;
-        if (TASK != DRONE_TASK_WAYPOINT) {
+        if (TASK != DRONE_TASK_WAYPOINT && TASK != DRONE_TASK_RACE) {
             score = (float)L.score_count / (float)L.tick;
             perf = score;
         } else {
@@ -264,7 +310,7 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
         out.ep_return = L.ep_return;
         out.ep_len = (float)L.tick;
         L.episode += 1u;
-        lane_reset(P, L, env);
+        lane_reset<TASK>(P, L, env);
         target_changed = true;
     }
     out.target_changed = target_changed;
@@ -306,6 +352,20 @@ DRONE_FN void lane_obs(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM
     o[16] = fma_(r02, ex, fma_(r12, ey, r22 * ez)) * P.half_inv_bound;
 #pragma unroll
     for (int i = 0; i < 3; i++) o[17 + i] = L.s.p[i] * P.inv_bound;
+}
+
+// SPEC.md §11 step 10: gate normal in the body frame, signed distance to the gate plane.
+DRONE_FN void lane_obs_gate(const KParams& P, const Lane& L, float (&o)[DRONE_OBS_DIM_MAX]) {
+    const float w = L.s.q[0], x = L.s.q[1], y = L.s.q[2], z = L.s.q[3];
+    const float r00 = fma_(-2.0f, fma_(y, y, z * z), 1.0f), r01 = 2.0f * fma_(x, y, -(w * z)), r02 = 2.0f * fma_(x, z, w * y);
+    const float r10 = 2.0f * fma_(x, y, w * z), r11 = fma_(-2.0f, fma_(x, x, z * z), 1.0f), r12 = 2.0f * fma_(y, z, -(w * x));
+    const float r20 = 2.0f * fma_(x, z, -(w * y)), r21 = 2.0f * fma_(y, z, w * x), r22 = fma_(-2.0f, fma_(x, x, y * y), 1.0f);
+    const float(&n)[3] = L.wind;
+    o[20] = fma_(r00, n[0], fma_(r10, n[1], r20 * n[2]));
+    o[21] = fma_(r01, n[0], fma_(r11, n[1], r21 * n[2]));
+    o[22] = fma_(r02, n[0], fma_(r12, n[1], r22 * n[2]));
+    const float d[3] = {L.s.p[0] - L.tgt[0], L.s.p[1] - L.tgt[1], L.s.p[2] - L.tgt[2]};
+    o[23] = dot3(n, d) * P.inv_bound;
 }
 
 // SPEC.md §10 step 10: the four neighbour observations (rows of 24 floats).

@@ -31,7 +31,7 @@ enum Plane : int {
     kP3 = 3,    // om.z rpm0 rpm1 rpm2
     kP4 = 4,    // rpm3 ep_return tick(u32) score_count(u32)
     kPT = 5,    // target.x target.y target.z episode(u32)   — written only when it changes
-    kPW = 6,    // wind.x wind.y wind.z (pad)               — task 1 only
+    kPW = 6,    // aux: wind.xyz (task 1) / gate normal (task 3)  — tasks 1 and 3 only
     kL0 = 7,    // perf_sum score_sum ret_sum len_sum        — touched only when an episode ends
     kL1 = 8,    // n_sum oob_sum (pad) (pad)
     kNumPlanes = 9
@@ -58,12 +58,12 @@ struct KParams {
     float wind_decay, wind_gain, wind_max;
     float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
     float coll_r2, inv_prox_r2, nn_far2, c_proximity;  // task 2 (SPEC.md §10)
+    float gate_r2;                                      // task 3 (SPEC.md §11)
     // integers
     uint32_t horizon, substeps;
     uint32_t key_reset, key_action, key_wind, key_waypoint;
     uint32_t env_offset;
     uint32_t agents;  // drones per swarm (task 2), else 1
-    uint32_t pad_;
 };
 static_assert(sizeof(KParams) == 56 * 4, "KParams is passed / staged as 56 words");
 constexpr int kParamWords = 56;
@@ -141,6 +141,7 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.inv_prox_r2 = 1.0f / (c.proximity_radius * c.proximity_radius);
     p.nn_far2 = (4.0f * c.bound) * (4.0f * c.bound);
     p.c_proximity = c.c_proximity;
+    p.gate_r2 = c.gate_radius * c.gate_radius;
     p.horizon = (uint32_t)c.horizon;
     p.substeps = (uint32_t)c.substeps;
     p.key_reset = stream_key(seed, kReset);
@@ -149,7 +150,6 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.key_waypoint = stream_key(seed, kWaypoint);
     p.env_offset = c.env_offset;
     p.agents = c.task == DRONE_TASK_SWARM ? (uint32_t)c.agents_per_env : 1u;
-    p.pad_ = 0;
 }
 
 }  // namespace drone

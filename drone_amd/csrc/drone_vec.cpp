@@ -105,7 +105,7 @@ bool validate(const DroneConfig* c, int num_envs) {
     if (!c) { set_err("config is NULL"); return false; }
     if (c->struct_size != sizeof(DroneConfig)) { set_err("DroneConfig.struct_size %u != %zu", c->struct_size, sizeof(DroneConfig)); return false; }
     if (num_envs <= 0) { set_err("num_envs must be positive"); return false; }
-    if (c->task != DRONE_TASK_HOVER && c->task != DRONE_TASK_WAYPOINT && c->task != DRONE_TASK_SWARM) { set_err("unknown task %d", c->task); return false; }
+    if (c->task != DRONE_TASK_HOVER && c->task != DRONE_TASK_WAYPOINT && c->task != DRONE_TASK_SWARM && c->task != DRONE_TASK_RACE) { set_err("unknown task %d", c->task); return false; }
     if (c->task == DRONE_TASK_SWARM) {
         const int A = c->agents_per_env;
         if (A < 1 || A > 64 || (A & (A - 1))) { set_err("agents_per_env must be a power of two in [1, 64], got %d", A); return false; }
@@ -240,9 +240,10 @@ void drone_config_default(DroneConfig* c, int task) {
     c->collision_radius = 0.15f;
     c->proximity_radius = 1.0f;
     c->c_proximity = 0.5f;
+    c->gate_radius = 0.75f;
 }
 
-int drone_obs_dim(int task) { return task == DRONE_TASK_SWARM ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
+int drone_obs_dim(int task) { return (task == DRONE_TASK_SWARM || task == DRONE_TASK_RACE) ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
 
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, unsigned char* terminals,
                          unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {

@@ -32,7 +32,7 @@ class Drone:
         ``actions``, ``rewards``, ``terminals``, ``truncations`` arrays (numpy for the host
         path, torch CUDA tensors for the device path), e.g. a worker's slice of the
         vec-env's shared memory. Without it the env allocates its own."""
-        task_id = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT, "swarm": abi.TASK_SWARM}[task] if isinstance(task, str) else int(task)
+        task_id = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT, "swarm": abi.TASK_SWARM, "race": abi.TASK_RACE}[task] if isinstance(task, str) else int(task)
         buffers = None if buf is None else (buf.observations, buf.actions, buf.rewards, buf.terminals, buf.truncations)
         self.vec = binding.DroneVec(num_envs, seed=seed, task=task_id, device=device, buffers=buffers, **config)
         self.num_agents = self.vec.num_envs

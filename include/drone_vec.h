@@ -30,12 +30,13 @@ extern "C" {
 #endif
 
 #define DRONE_OBS_DIM 20     /* observation floats per env row, tasks 0 and 1 */
-#define DRONE_OBS_DIM_MAX 24 /* task 2 appends the nearest neighbour (3 + 1) */
+#define DRONE_OBS_DIM_MAX 24 /* tasks 2 and 3 append four floats: nearest neighbour / gate normal and plane distance */
 #define DRONE_ACT_DIM 4
 
 #define DRONE_TASK_HOVER 0
 #define DRONE_TASK_WAYPOINT 1 /* waypoint tracking with OU wind gusts */
 #define DRONE_TASK_SWARM 2    /* agents_per_env drones per env, coupled by a nearest-neighbour term (SPEC.md §10) */
+#define DRONE_TASK_RACE 3     /* fly through a sequence of ring gates (SPEC.md §11) */
 
 #define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory: registered + mapped, the kernel accesses them over PCIe (fallback: H2D, kernel, D2H); step ends with a sync */
 #define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
@@ -60,6 +61,7 @@ typedef struct DroneConfig {
     float wind_theta, wind_sigma, wind_max;
     float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
     float collision_radius, proximity_radius, c_proximity; /* task 2 */
+    float gate_radius;                                      /* task 3 */
 } DroneConfig;
 
 /* Aggregated episode statistics since the previous drone_vec_log (SPEC.md §8). */
@@ -76,7 +78,7 @@ typedef struct DroneLog {
  * the device keeps state as float4 planes. */
 typedef struct DroneStateRow {
     float pos[3], vel[3], quat[4], omega[3], rpm[4];
-    float target[3], wind[3];
+    float target[3], wind[3]; /* task 3: target = gate centre, wind = gate normal */
     float ep_return;
     uint32_t tick, episode, score_count;
     float perf_sum, score_sum, ret_sum, len_sum, n_sum, oob_sum;
@@ -86,7 +88,7 @@ typedef struct DroneVec DroneVec;
 
 void drone_config_default(DroneConfig* cfg, int task);
 
-/* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM. */
+/* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM and DRONE_TASK_RACE. */
 int drone_obs_dim(int task);
 
 /* observations [N][drone_obs_dim(task)] f32, actions [N][4] f32, rewards [N] f32,

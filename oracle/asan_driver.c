@@ -13,13 +13,14 @@ void oracle_vec_log(OracleVec*, DroneLog*);
 void oracle_vec_close(OracleVec*);
 uint32_t oracle_vec_gstep(const OracleVec*);
 int main(void) {
-    for (int task = 0; task < 3; task++) {
+    for (int task = 0; task < 4; task++) {
         const int n = task == 2 ? 256 : 257;
         DroneConfig c;
         oracle_config_default(&c, task);
         c.horizon = 64;
         c.collision_radius = 0.6f;
-        float* obs = malloc(sizeof(float) * n * (task == 2 ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM));
+        c.gate_radius = 3.0f;
+        float* obs = malloc(sizeof(float) * n * (task >= 2 ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM));
         float* act = malloc(sizeof(float) * n * DRONE_ACT_DIM);
         float* rew = malloc(sizeof(float) * n);
         unsigned char* term = malloc(n);

@@ -47,6 +47,7 @@ typedef struct Params {
     float inv_bound, half_inv_bound;
     float wind_decay, wind_gain;
     float coll_r2, inv_prox_r2, nn_far2;
+    float gate_r2;
 } Params;
 
 static inline void params_derive(const DroneConfig* c, Params* p) {
@@ -86,6 +87,7 @@ static inline void params_derive(const DroneConfig* c, Params* p) {
     p->coll_r2 = c->collision_radius * c->collision_radius;
     p->inv_prox_r2 = 1.0f / (c->proximity_radius * c->proximity_radius);
     p->nn_far2 = (4.0f * c->bound) * (4.0f * c->bound);
+    p->gate_r2 = c->gate_radius * c->gate_radius;
 }
 
 /* SPEC.md §2 */
@@ -141,10 +143,12 @@ typedef struct Drone {
     unsigned char* truncations;
     State s;
     float target[3], wind[3];
+    float gate_n[3]; /* task 3: unit normal of the current gate (its centre is `target`) */
     float ep_return;
     uint32_t tick, episode, score_count;
     uint32_t env_id; /* global id */
     float scratch_a2, scratch_prev_dist; /* carried from step_integrate to step_finish */
+    float scratch_p0[3];                 /* task 3: position before integrating */
     /* shared, read-only */
     const DroneConfig* cfg;
     const Params* par;
@@ -261,6 +265,14 @@ static inline void compute_observations(Drone* env) {
     (void)c;
 }
 
+static inline float dot3(const float a[3], const float b[3]) { return fmaf(a[0], b[0], fmaf(a[1], b[1], a[2] * b[2])); }
+
+/* SPEC.md §11: unit(e) */
+static inline void unit3(const float e[3], float out[3]) {
+    const float inv = 1.0f / sqrtf(dot3(e, e) + 1e-12f);
+    for (int i = 0; i < 3; i++) out[i] = e[i] * inv;
+}
+
 /* SPEC.md §6 (state only; the episode counter is the caller's business) */
 static inline void reset_state(Drone* env) {
     const DroneConfig* c = env->cfg;
@@ -286,6 +298,11 @@ static inline void reset_state(Drone* env) {
     env->tick = 0;
     env->score_count = 0;
     env->ep_return = 0.0f;
+    if (c->task == DRONE_TASK_RACE) { /* SPEC.md §11: gate 0 faces the spawn point */
+        float e[3];
+        for (int i = 0; i < 3; i++) e[i] = env->target[i] - env->s.pos[i];
+        unit3(e, env->gate_n);
+    }
 }
 
 static inline void init(Drone* env) {
@@ -294,12 +311,15 @@ static inline void init(Drone* env) {
     env->episode = 0;
 }
 
+static inline void race_observations(Drone* env);
+
 /* First episode of this env (vec_reset): SPEC.md §6 last paragraph. */
 static inline void c_reset(Drone* env) {
     memset(&env->log, 0, sizeof(Log));
     env->episode = 0;
     reset_state(env);
     compute_observations(env);
+    if (env->cfg->task == DRONE_TASK_RACE) race_observations(env);
     env->rewards[0] = 0.0f;
     env->terminals[0] = 0;
     env->truncations[0] = 0;
@@ -327,6 +347,10 @@ static inline void step_integrate(Drone* env) {
             const float xi = (float)((int)sum - 510);
             env->wind[i] = clampc(fmaf(p->wind_decay, env->wind[i], p->wind_gain * xi), -c->wind_max, c->wind_max);
         }
+        env->scratch_prev_dist = target_dist(env);
+    }
+    if (c->task == DRONE_TASK_RACE) {
+        for (int i = 0; i < 3; i++) env->scratch_p0[i] = s->pos[i];
         env->scratch_prev_dist = target_dist(env);
     }
     for (int k = 0; k < c->substeps; k++) rk4_substep(env, ct);
@@ -376,7 +400,32 @@ static inline void step_finish(Drone* env, float nn_d2) {
     const float w2 = fmaf(s->omega[0], s->omega[0], fmaf(s->omega[1], s->omega[1], s->omega[2] * s->omega[2]));
     const float pen = fmaf(c->c_omega, w2, c->c_action * env->scratch_a2);
     float r;
-    if (c->task != DRONE_TASK_WAYPOINT) {
+    if (c->task == DRONE_TASK_RACE) {
+        r = c->progress_scale * (env->scratch_prev_dist - dist) - pen;
+        float d0[3], d1[3];
+        for (int i = 0; i < 3; i++) {
+            d0[i] = env->scratch_p0[i] - env->target[i];
+            d1[i] = s->pos[i] - env->target[i];
+        }
+        const float s0 = dot3(env->gate_n, d0), s1 = dot3(env->gate_n, d1);
+        if (!oob && s0 < 0.0f && s1 >= 0.0f) { /* crossed the gate plane forwards */
+            const float t = s0 / (s0 - s1);
+            float m[3];
+            for (int i = 0; i < 3; i++) m[i] = fmaf(t, s->pos[i] - env->scratch_p0[i], env->scratch_p0[i]) - env->target[i];
+            if (dot3(m, m) < p->gate_r2) { /* through the ring */
+                r += c->waypoint_bonus;
+                env->score_count += 1;
+                const uint32_t b = rng_base(env->keys[STREAM_WAYPOINT], env->env_id, env->episode);
+                float cn[3], e[3];
+                for (uint32_t i = 0; i < 3; i++) {
+                    cn[i] = c->target_extent * sym(rng_draw(b, 3u * env->score_count + i));
+                    e[i] = cn[i] - env->target[i];
+                }
+                unit3(e, env->gate_n);
+                for (int i = 0; i < 3; i++) env->target[i] = cn[i];
+            }
+        }
+    } else if (c->task != DRONE_TASK_WAYPOINT) {
         r = fmaf(-p->half_inv_bound, dist, 1.0f) - pen;
         if (dist < c->hover_radius) env->score_count += 1;
         if (c->task == DRONE_TASK_SWARM) r = r - c->c_proximity * fmax_(0.0f, fmaf(-nn_d2, p->inv_prox_r2, 1.0f));
@@ -399,7 +448,7 @@ static inline void step_finish(Drone* env, float nn_d2) {
 
     if (oob || trunc) {
         float score, perf;
-        if (c->task != DRONE_TASK_WAYPOINT) {
+        if (c->task != DRONE_TASK_WAYPOINT && c->task != DRONE_TASK_RACE) {
             score = (float)env->score_count / (float)env->tick;
             perf = score;
         } else {
@@ -434,11 +483,29 @@ static inline void swarm_observations(Drone* swarm, int A, int i) {
     o[23] = (nn_d2 * p->inv_bound) * p->inv_bound;
 }
 
-/* One step of a single-agent env (tasks 0 and 1): SPEC.md §5. */
+/* SPEC.md §11 step 10: the gate normal in the body frame and the signed distance to its plane. */
+static inline void race_observations(Drone* env) {
+    const Params* p = env->par;
+    const float w = env->s.quat[0], x = env->s.quat[1], y = env->s.quat[2], z = env->s.quat[3];
+    const float r00 = fmaf(-2.0f, fmaf(y, y, z * z), 1.0f), r01 = 2.0f * fmaf(x, y, -(w * z)), r02 = 2.0f * fmaf(x, z, w * y);
+    const float r10 = 2.0f * fmaf(x, y, w * z), r11 = fmaf(-2.0f, fmaf(x, x, z * z), 1.0f), r12 = 2.0f * fmaf(y, z, -(w * x));
+    const float r20 = 2.0f * fmaf(x, z, -(w * y)), r21 = 2.0f * fmaf(y, z, w * x), r22 = fmaf(-2.0f, fmaf(x, x, y * y), 1.0f);
+    const float* n = env->gate_n;
+    float* o = env->observations;
+    o[20] = fmaf(r00, n[0], fmaf(r10, n[1], r20 * n[2]));
+    o[21] = fmaf(r01, n[0], fmaf(r11, n[1], r21 * n[2]));
+    o[22] = fmaf(r02, n[0], fmaf(r12, n[1], r22 * n[2]));
+    float d[3];
+    for (int i = 0; i < 3; i++) d[i] = env->s.pos[i] - env->target[i];
+    o[23] = dot3(n, d) * p->inv_bound;
+}
+
+/* One step of a single-agent env (tasks 0, 1 and 3): SPEC.md §5, §11. */
 static inline void c_step(Drone* env) {
     step_integrate(env);
     step_finish(env, 0.0f);
     compute_observations(env);
+    if (env->cfg->task == DRONE_TASK_RACE) race_observations(env);
 }
 
 /* One step of a swarm of A agents (task 2): SPEC.md §10. */

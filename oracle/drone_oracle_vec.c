@@ -76,9 +76,10 @@ void oracle_config_default(DroneConfig* c, int task) {
     c->collision_radius = 0.15f;
     c->proximity_radius = 1.0f;
     c->c_proximity = 0.5f;
+    c->gate_radius = 0.75f;
 }
 
-int oracle_obs_dim(int task) { return task == DRONE_TASK_SWARM ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
+int oracle_obs_dim(int task) { return (task == DRONE_TASK_SWARM || task == DRONE_TASK_RACE) ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
 
 static void set_keys(OracleVec* v, uint64_t seed) {
     for (uint32_t s = 0; s < 4; s++) v->keys[s] = stream_key(seed, s);
@@ -227,7 +228,7 @@ int oracle_vec_get_state(OracleVec* v, DroneStateRow* rows, int first, int count
         DroneStateRow* r = &rows[i];
         memcpy(r->pos, e->s.pos, sizeof(State)); /* pos vel quat omega rpm are contiguous in both */
         memcpy(r->target, e->target, 12);
-        memcpy(r->wind, e->wind, 12);
+        memcpy(r->wind, v->cfg.task == DRONE_TASK_RACE ? e->gate_n : e->wind, 12); /* the aux slots */
         r->ep_return = e->ep_return;
         r->tick = e->tick;
         r->episode = e->episode;
@@ -249,7 +250,8 @@ int oracle_vec_set_state(OracleVec* v, const DroneStateRow* rows, int first, int
         const DroneStateRow* r = &rows[i];
         memcpy(e->s.pos, r->pos, sizeof(State));
         memcpy(e->target, r->target, 12);
-        memcpy(e->wind, r->wind, 12);
+        if (v->cfg.task == DRONE_TASK_RACE) memcpy(e->gate_n, r->wind, 12);
+        else memcpy(e->wind, r->wind, 12);
         e->ep_return = r->ep_return;
         e->tick = r->tick;
         e->episode = r->episode;
@@ -270,10 +272,10 @@ uint32_t oracle_stream_key(uint64_t seed, uint32_t stream) { return stream_key(s
 uint32_t oracle_rng_draw(uint32_t key, uint32_t env, uint32_t ctr, uint32_t d) {
     return rng_draw(rng_base(key, env, ctr), d);
 }
-void oracle_params_derive(const DroneConfig* c, float* out30) {
+void oracle_params_derive(const DroneConfig* c, float* out31) {
     Params p;
     params_derive(c, &p);
-    memcpy(out30, &p, sizeof(Params));
+    memcpy(out31, &p, sizeof(Params));
 }
 int oracle_omp_max_threads(void) {
 #ifdef _OPENMP

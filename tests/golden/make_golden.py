@@ -48,7 +48,7 @@ def run(task, horizon, env_offset, **extra):
 
 def main():
     for name, task, horizon, off, extra in (("hover", 0, 1024, 0, {}), ("waypoint", 1, 1024, 0, {}), ("hover_h100_off", 0, 100, 1 << 20, {}),
-                                             ("swarm", 2, 300, 64, {"collision_radius": 0.5})):
+                                             ("swarm", 2, 300, 64, {"collision_radius": 0.5}), ("race", 3, 200, 0, {"gate_radius": 2.5})):
         np.savez_compressed(os.path.join(HERE, f"golden_{name}.npz"), **run(task, horizon, off, **extra))
         print("wrote", name)
 

@@ -40,10 +40,11 @@ static void group_neighbour(const KParams& P, const std::vector<Lane>& lanes, in
 }
 
 static void write_obs(const DroneConfig* cfg, const KParams& P, const std::vector<Lane>& lanes, float* obs) {
-    const int od = cfg->task == DRONE_TASK_SWARM ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM;
+    const int od = (cfg->task == DRONE_TASK_SWARM || cfg->task == DRONE_TASK_RACE) ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM;
     for (size_t i = 0; i < lanes.size(); i++) {
         float o[DRONE_OBS_DIM_MAX];
         lane_obs(P, lanes[i], o);
+        if (cfg->task == DRONE_TASK_RACE) lane_obs_gate(P, lanes[i], o);
         if (cfg->task == DRONE_TASK_SWARM) {
             float nn_d2, nn_e[3];
             group_neighbour(P, lanes, (int)i, nn_d2, nn_e);
@@ -60,7 +61,8 @@ void lane_host_reset(const DroneConfig* cfg, uint64_t seed, DroneStateRow* rows,
     for (int i = 0; i < n; i++) {
         memset(&rows[i], 0, sizeof(DroneStateRow));
         lanes[i].episode = 0;
-        lane_reset(P, lanes[i], P.env_offset + (uint32_t)i);
+        if (cfg->task == DRONE_TASK_RACE) lane_reset<DRONE_TASK_RACE>(P, lanes[i], P.env_offset + (uint32_t)i);
+        else lane_reset(P, lanes[i], P.env_offset + (uint32_t)i);
         lane_to_row(lanes[i], rows[i]);
     }
     write_obs(cfg, P, lanes, obs);
@@ -87,6 +89,7 @@ void lane_host_step(const DroneConfig* cfg, uint64_t seed, uint32_t gstep, Drone
         }
         if (cfg->task == DRONE_TASK_HOVER) lane_step<DRONE_TASK_HOVER>(P, lanes[i], act, env, gstep, outs[i]);
         else if (cfg->task == DRONE_TASK_WAYPOINT) lane_step<DRONE_TASK_WAYPOINT>(P, lanes[i], act, env, gstep, outs[i]);
+        else if (cfg->task == DRONE_TASK_RACE) lane_step<DRONE_TASK_RACE>(P, lanes[i], act, env, gstep, outs[i]);
         else lane_integrate<DRONE_TASK_SWARM>(P, lanes[i], act, env, gstep, ctx[i]);
     }
     if (cfg->task == DRONE_TASK_SWARM) {

@@ -29,7 +29,7 @@ def p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-@pytest.mark.parametrize("task,horizon,substeps", [(0, 1024, 1), (1, 1024, 1), (0, 37, 1), (1, 41, 2), (2, 1024, 1), (2, 60, 2)])
+@pytest.mark.parametrize("task,horizon,substeps", [(0, 1024, 1), (1, 1024, 1), (0, 37, 1), (1, 41, 2), (2, 1024, 1), (2, 60, 2), (3, 1024, 1), (3, 50, 3)])
 def test_lane_math_bit_exact_vs_oracle(lane, oracle, task, horizon, substeps):
     n, seed = 1024, 4242
     extra = dict(collision_radius=0.6, agents_per_env=16, env_offset=784) if task == 2 else dict(env_offset=777)
@@ -66,10 +66,10 @@ def test_kparams_match_oracle_params(lane, oracle):
     lane.lane_host_kparams(C.byref(cfg), C.c_uint64(9), p(kp))
     f = kp.view(np.float32)
     # oracle Params order -> KParams word index
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27, 28, 35, 36, 43, 44, 45]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27, 28, 35, 36, 43, 44, 45, 47]
     assert_bits_equal(want, f[idx].copy(), "derived params")
     keys = [oracle.lib().oracle_stream_key(9, s) for s in range(4)]
-    assert list(kp[49:53]) == keys
+    assert list(kp[50:54]) == keys
 
 
 def test_random_configs_bit_exact(lane, oracle):
@@ -78,7 +78,7 @@ def test_random_configs_bit_exact(lane, oracle):
     rng = np.random.default_rng(123)
     n = 256
     for trial in range(20):
-        task = trial % 3
+        task = trial % 4
         over = dict(
             horizon=int(rng.integers(5, 120)), substeps=int(rng.integers(1, 4)), dt=float(rng.uniform(0.002, 0.03)),
             mass=float(rng.uniform(0.02, 1.5)), arm=float(rng.uniform(0.03, 0.3)),
@@ -93,7 +93,7 @@ def test_random_configs_bit_exact(lane, oracle):
             c_omega=float(rng.uniform(0, 1e-3)), c_action=float(rng.uniform(0, 0.1)), crash_penalty=float(rng.uniform(0, 5)),
             progress_scale=float(rng.uniform(0.1, 3)), waypoint_bonus=float(rng.uniform(0, 3)),
             env_offset=int(rng.integers(0, 2**25)) * 64, agents_per_env=int(2 ** rng.integers(0, 7)),
-            collision_radius=float(rng.uniform(0.05, 1.0)), proximity_radius=float(rng.uniform(0.3, 3.0)), c_proximity=float(rng.uniform(0, 2)))
+            collision_radius=float(rng.uniform(0.05, 1.0)), proximity_radius=float(rng.uniform(0.3, 3.0)), c_proximity=float(rng.uniform(0, 2)), gate_radius=float(rng.uniform(0.2, 3.0)))
         seed = int(rng.integers(0, 2**63))
         cfg = oracle.default_config(task, **over)
         v = oracle.OracleVec(n, seed=seed, cfg=cfg)
@@ -114,3 +114,39 @@ def test_random_configs_bit_exact(lane, oracle):
             assert_bits_equal(v.observations, obs, f"trial {trial} obs {t}")
             assert_bits_equal(v.rewards, rew, f"trial {trial} rew {t}")
         assert_state_equal(v.get_state(), rows, f"trial {trial} final")
+
+
+def test_race_forced_gate_passes(lane, oracle):
+    """Gate passes are rare under the random policy: steer every drone through its gate
+    (and some past it) and compare lane math with the oracle on exactly those steps."""
+    n, seed = 512, 99
+    cfg = oracle.default_config(3, gate_radius=1.0, horizon=500)
+    v = oracle.OracleVec(n, seed=seed, cfg=cfg)
+    v.reset(seed)
+    obs = np.zeros((n, 24), np.float32)
+    act = np.zeros((n, 4), np.float32)
+    rew = np.zeros(n, np.float32)
+    term = np.zeros(n, np.uint8)
+    trunc = np.zeros(n, np.uint8)
+    rng = np.random.default_rng(5)
+    passes = 0
+    for rnd in range(12):
+        st = v.get_state()
+        nrm, c = st["wind"], st["target"]
+        side = np.cross(nrm, np.array([0.3, -0.5, 0.8], np.float32)).astype(np.float32)
+        st["pos"] = (c - rng.uniform(0.0, 0.08, (n, 1)).astype(np.float32) * nrm + rng.uniform(0, 1.6, (n, 1)).astype(np.float32) * side).astype(np.float32)
+        st["vel"] = (rng.uniform(2, 8, (n, 1)).astype(np.float32) * nrm).astype(np.float32)
+        v.set_state(st)
+        rows = v.get_state()
+        before = rows["score_count"].copy()
+        for t in range(3):
+            v.fill_random_actions()
+            g = v.gstep
+            v.step()
+            lane.lane_host_step(C.byref(cfg), C.c_uint64(seed), C.c_uint32(g), p(rows), p(act), p(obs), p(rew), p(term), p(trunc), n, 1)
+            assert_bits_equal(v.observations, obs, f"obs round {rnd} step {t}")
+            assert_bits_equal(v.rewards, rew, f"rew round {rnd} step {t}")
+        assert_state_equal(v.get_state(), rows, f"round {rnd}")
+        passes += int((rows["score_count"] > before).sum())
+    assert passes > n  # both outcomes occur: passes and misses
+    assert passes < 12 * n

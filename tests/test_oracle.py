@@ -90,7 +90,7 @@ def test_reset_known_answers(oracle):
 
 
 GOLDEN_CASES = [("hover", 0, 1024, 0, {}), ("waypoint", 1, 1024, 0, {}), ("hover_h100_off", 0, 100, 1 << 20, {}),
-                ("swarm", 2, 300, 64, {"collision_radius": 0.5})]
+                ("swarm", 2, 300, 64, {"collision_radius": 0.5}), ("race", 3, 200, 0, {"gate_radius": 2.5})]
 
 
 @pytest.mark.parametrize("name,task,horizon,off,extra", GOLDEN_CASES)
@@ -287,3 +287,49 @@ def test_swarm_rejects_bad_grouping(oracle):
         oracle.OracleVec(64, cfg=oracle.default_config(2, agents_per_env=6))    # not a power of two
     with pytest.raises(RuntimeError):
         oracle.OracleVec(64, cfg=oracle.default_config(2, agents_per_env=8, env_offset=4))
+
+
+def _toward_gates(v, offset, speed, lateral=0.0):
+    """Place every drone `offset` metres behind its gate plane (plus `lateral` metres off-axis), flying along +n."""
+    st = v.get_state()
+    n, c = st["wind"].copy(), st["target"].copy()
+    side = np.cross(n, np.array([0.3, -0.5, 0.8], np.float32))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    st["pos"] = c - offset * n + lateral * side
+    st["vel"] = speed * n
+    st["omega"] = 0
+    v.set_state(st)
+    return st
+
+
+def test_race_gate_passing(oracle):
+    """SPEC.md §11: forward crossing inside the ring scores and deals the next gate;
+    a crossing outside the ring or backwards does not."""
+    n = 256
+    cfg = oracle.default_config(3, gate_radius=0.75, bound=50.0, horizon=10_000)
+    v = oracle.OracleVec(n, seed=12, cfg=cfg)
+    v.reset(12)
+    st0 = v.get_state()
+    np.testing.assert_allclose(np.linalg.norm(st0["wind"].astype(np.float64), axis=1), 1.0, atol=1e-6)
+    # through the middle
+    before = _toward_gates(v, 0.03, 6.0)
+    v.actions[:] = 0.3
+    v.step()
+    st = v.get_state()
+    assert np.all(st["score_count"] == 1) and np.all(v.rewards > 0.9)
+    assert not np.array_equal(st["target"], before["target"])
+    np.testing.assert_allclose(np.linalg.norm(st["wind"].astype(np.float64), axis=1), 1.0, atol=1e-6)
+    want_n = (st["target"] - before["target"]).astype(np.float64)
+    want_n /= np.linalg.norm(want_n, axis=1, keepdims=True)
+    np.testing.assert_allclose(st["wind"], want_n, atol=1e-6)
+    # signed plane distance of the NEW gate in obs[23]
+    d = ((st["pos"] - st["target"]).astype(np.float64) * st["wind"]).sum(1) / 50.0
+    np.testing.assert_allclose(v.observations[:, 23], d, atol=1e-6)
+    # outside the ring: a miss
+    _toward_gates(v, 0.03, 6.0, lateral=1.0)
+    v.step()
+    assert np.all(v.get_state()["score_count"] == 1)
+    # backwards through the ring: nothing
+    _toward_gates(v, -0.03, -6.0)
+    v.step()
+    assert np.all(v.get_state()["score_count"] == 1) and v.terminals.sum() == 0

@@ -410,7 +410,7 @@ def test_random_configs_random_sizes(oracle, hip):
 
     rng = np.random.default_rng(int(os.environ.get("DRONE_FUZZ_SEED", "2025")))
     for trial in range(int(os.environ.get("DRONE_FUZZ_TRIALS", "30"))):
-        task = trial % 3
+        task = trial % 4
         A = int(2 ** rng.integers(0, 7)) if task == 2 else 1
         n = int(rng.integers(1, 40)) * A * int(rng.integers(1, 30))
         over = dict(
@@ -427,7 +427,7 @@ def test_random_configs_random_sizes(oracle, hip):
             c_omega=float(rng.uniform(0, 1e-3)), c_action=float(rng.uniform(0, 0.1)), crash_penalty=float(rng.uniform(0, 5)),
             progress_scale=float(rng.uniform(0.1, 3)), waypoint_bonus=float(rng.uniform(0, 3)),
             agents_per_env=A, collision_radius=float(rng.uniform(0.05, 1.0)), proximity_radius=float(rng.uniform(0.3, 3.0)),
-            c_proximity=float(rng.uniform(0, 2)), env_offset=int(rng.integers(0, 2**24)) * 64,
+            c_proximity=float(rng.uniform(0, 2)), gate_radius=float(rng.uniform(0.2, 3.0)), env_offset=int(rng.integers(0, 2**24)) * 64,
             compact_done=int(rng.integers(0, 2)))
         seed = int(rng.integers(0, 2**63))
         o, h = make_pair(oracle, hip, n, seed, task, **over)
@@ -443,3 +443,43 @@ def test_random_configs_random_sizes(oracle, hip):
         assert_state_equal(o.get_state(), h.get_state(), f"trial {trial} state")
         h.close()
         o.close()
+
+
+@pytest.mark.parametrize("device", [None, "cuda:0"])
+def test_race_task_bit_exact_with_forced_gate_passes(oracle, hip, device):
+    """Task 3 (SPEC.md §11): random-policy steps plus rounds in which every drone is steered at
+    its gate (through it, past its rim, or not quite reaching it), per-step and fused."""
+    n, seed = 3000, 808
+    o, h = make_pair(oracle, hip, n, seed, 3, device=device, gate_radius=1.0, horizon=400)
+    assert to_np(h.observations).shape == (n, 24)
+    assert_outputs_equal(o, h, "race reset")
+    rng = np.random.default_rng(11)
+    passes = 0
+    for rnd in range(10):
+        st = o.get_state()
+        nrm, c = st["wind"], st["target"]
+        side = np.cross(nrm, np.array([0.3, -0.5, 0.8], np.float32)).astype(np.float32)
+        st["pos"] = (c - rng.uniform(0.0, 0.08, (n, 1)).astype(np.float32) * nrm + rng.uniform(0, 1.6, (n, 1)).astype(np.float32) * side).astype(np.float32)
+        st["vel"] = (rng.uniform(2, 8, (n, 1)).astype(np.float32) * nrm).astype(np.float32)
+        o.set_state(st)
+        h.set_state(st)
+        before = st["score_count"].copy()
+        for t in range(4):
+            o.fill_random_actions()
+            if device is None:
+                set_actions(h, o.actions)
+            else:
+                h.fill_random_actions()
+            o.step()
+            h.step()
+            assert_outputs_equal(o, h, f"race round {rnd} step {t}")
+        so = o.get_state()
+        assert_state_equal(so, h.get_state(), f"race round {rnd}")
+        passes += int((so["score_count"] > before).sum())
+        if rnd % 3 == 2:
+            o.rollout(20)
+            h.rollout(20)
+            assert_outputs_equal(o, h, f"race fused after round {rnd}")
+    assert n < passes < 10 * n
+    lo, lh = o.log(), h.log()
+    assert lo["n"] == lh["n"]

@@ -38,7 +38,7 @@ def main():
 
     from drone_amd import abi, binding
 
-    task = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT, "swarm": abi.TASK_SWARM}[a.task]
+    task = {"hover": abi.TASK_HOVER, "waypoint": abi.TASK_WAYPOINT, "swarm": abi.TASK_SWARM, "race": abi.TASK_RACE}[a.task]
     specs = {}
     for spec in a.variants:
         name, _, rest = spec.partition("=")
