@@ -227,9 +227,10 @@ def test_lds_constants_variant(oracle, hip, tmp_path):
     subprocess.run(["make", "-s", "-C", os.path.join(root, "drone_amd", "csrc"), "-B", f"OUT={lib}", "EXTRA=-DDRONE_PARAMS_IN_LDS=1"],
                    check=True, capture_output=True)
     fns = hip.load_variant(lib)
-    for task in (0, 1):
-        o = oracle.OracleVec(3001, seed=6, cfg=oracle.default_config(task, horizon=90), threads=8)
-        h = hip.DroneVec(3001, seed=6, cfg=hip.default_config(task, horizon=90), fns=fns)
+    for task in (0, 1, 2, 3):
+        n = 3008 if task == 2 else 3001
+        o = oracle.OracleVec(n, seed=6, cfg=oracle.default_config(task, horizon=90, collision_radius=0.5), threads=8)
+        h = hip.DroneVec(n, seed=6, cfg=hip.default_config(task, horizon=90, collision_radius=0.5), fns=fns)
         o.reset(6)
         h.reset(6)
         for t in range(200):
@@ -436,6 +437,9 @@ def test_random_configs_random_sizes(oracle, hip):
             set_actions(h, o.actions)
             o.step()
             h.step()
+            if over["compact_done"] and t % 7 == 0:
+                want = np.flatnonzero(o.terminals | o.truncations).astype(np.uint32)
+                assert_bits_equal(want, np.sort(h.done_list()), f"trial {trial} done ids step {t}")
         assert_outputs_equal(o, h, f"trial {trial} (task {task}, n {n}, A {A})")
         o.rollout(25)
         h.rollout(25)
