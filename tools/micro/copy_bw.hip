@@ -22,7 +22,25 @@ __global__ __launch_bounds__(256) void stream(const f4* __restrict__ in, f4* __r
     }
 }
 
+// same bytes, but the R (W) float4 of the 64 elements of a wave sit together: [wave tile][stream][lane]
+// -> one fat read stream and one fat write stream instead of R + W thin ones
 template <int R, int W, bool NT>
+__global__ __launch_bounds__(256) void stream_tiled(const f4* __restrict__ in, f4* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t tile = i >> 6, lane = i & 63;
+    f4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < R; r++) acc += in[(tile * R + r) * 64 + lane];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        f4 v = acc + (float)w;
+        if (NT) __builtin_nontemporal_store(v, &out[(tile * W + w) * 64 + lane]);
+        else out[(tile * W + w) * 64 + lane] = v;
+    }
+}
+
+template <int R, int W, bool NT, bool TILED = false>
 void run(const char* name, size_t n) {
     f4 *in, *out;
     hipMalloc(&in, sizeof(f4) * n * R);
@@ -32,9 +50,13 @@ void run(const char* name, size_t n) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int reps = 200;
-    for (int k = 0; k < 20; k++) stream<R, W, NT><<<(n + 255) / 256, 256>>>(in, out, n);
+    auto launch = [&]() {
+        if (TILED) stream_tiled<R, W, NT><<<(n + 255) / 256, 256>>>(in, out, n);
+        else stream<R, W, NT><<<(n + 255) / 256, 256>>>(in, out, n);
+    };
+    for (int k = 0; k < 20; k++) launch();
     hipEventRecord(e0);
-    for (int k = 0; k < reps; k++) stream<R, W, NT><<<(n + 255) / 256, 256>>>(in, out, n);
+    for (int k = 0; k < reps; k++) launch();
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -50,6 +72,8 @@ int main() {
     run<1, 1, false>("copy 1:1", n * 8);
     run<7, 10, false>("env-like 7:10 (112 B : 160 B)", n);
     run<7, 10, true>("env-like 7:10, nt stores", n);
+    run<7, 10, false, true>("env-like 7:10, wave-tiled layout", n);
+    run<7, 10, true, true>("env-like 7:10, wave-tiled, nt", n);
     run<9, 9, false>("9:9", n);
     run<0, 15, false>("write only (reset-like)", n);
     run<15, 1, false>("read mostly 15:1", n);
