@@ -10,6 +10,7 @@ import ctypes as C
 OBS_DIM = 20
 OBS_DIM_MAX = 24
 ACT_DIM = 4
+GATHER_ID_BYTES = 128
 TASK_HOVER = 0
 TASK_WAYPOINT = 1
 TASK_SWARM = 2
@@ -100,6 +101,14 @@ SYMBOLS = {
     "drone_vec_fill_random_actions": (C.c_int, [_P, _P, C.c_uint32]),
     "drone_vec_gstep": (C.c_uint32, [_P]),
     "drone_vec_num_envs": (C.c_int, [_P]),
+    "drone_vec_set_gstep": (C.c_int, [_P, C.c_uint32]),
+    "drone_vec_status": (C.c_int, [_P]),
+    "drone_vec_status_message": (C.c_char_p, [_P]),
+    "drone_vec_clear_status": (None, [_P]),
+    "drone_gather_unique_id": (C.c_int, [_P]),
+    "drone_vec_gather_init": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "drone_vec_gather": (C.c_int, [_P]),
+    "drone_vec_gather_close": (None, [_P]),
     "drone_vec_get_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "drone_vec_set_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "drone_vec_done_list": (C.c_int, [_P, _P, C.c_int]),

@@ -57,6 +57,15 @@ def default_config(task=abi.TASK_HOVER, **overrides):
     return cfg
 
 
+def gather_unique_id():
+    """128 opaque bytes naming a new RCCL communicator; one rank makes them, all ranks pass them to ``gather_init``."""
+    load()
+    buf = (C.c_ubyte * abi.GATHER_ID_BYTES)()
+    if _fns["drone_gather_unique_id"](C.cast(buf, C.c_void_p)) != 0:
+        raise RuntimeError("libdrone_hip: " + _fns["drone_last_error"]().decode())
+    return bytes(buf)
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -130,6 +139,8 @@ class DroneVec:
             n, seed, C.byref(self.cfg))
         if not self._h:
             raise RuntimeError("drone_vec_init failed: " + self._f["drone_last_error"]().decode())
+        self._step = self._f["drone_vec_step"]
+        self._status = self._f["drone_vec_status"]
         if self.torch_device is not None:
             self.use_torch_stream()
 
@@ -165,19 +176,31 @@ class DroneVec:
         if rc != 0:
             raise RuntimeError("libdrone_hip: " + self._f["drone_last_error"]().decode())
 
+    def _raise_if_failed(self):
+        """reset / step / rollout / log return void in the C-ABI (PufferLib's
+        convention); a failed launch or copy sticks to the handle instead."""
+        if self._status(self._h):
+            msg = self._f["drone_vec_status_message"](self._h).decode()
+            raise RuntimeError("libdrone_hip: " + msg)
+
     # -- the path --
     def reset(self, seed=0):
         self._f["drone_vec_reset"](self._h, seed)
+        self._raise_if_failed()
 
     def step(self):
-        self._f["drone_vec_step"](self._h)
+        self._step(self._h)
+        if self._status(self._h):
+            self._raise_if_failed()
 
     def rollout(self, horizon):
         self._f["drone_vec_rollout"](self._h, int(horizon))
+        self._raise_if_failed()
 
     def log(self):
         out = abi.DroneLog()
         self._f["drone_vec_log"](self._h, C.byref(out))
+        self._raise_if_failed()
         return out.as_dict()
 
     def close(self):
@@ -195,6 +218,35 @@ class DroneVec:
     @property
     def gstep(self):
         return self._f["drone_vec_gstep"](self._h)
+
+    def set_gstep(self, gstep):
+        self._check(self._f["drone_vec_set_gstep"](self._h, int(gstep)))
+
+    def status(self):
+        return self._f["drone_vec_status"](self._h), self._f["drone_vec_status_message"](self._h).decode()
+
+    def clear_status(self):
+        self._f["drone_vec_clear_status"](self._h)
+
+    # -- host-boundary all-gather through the C-ABI (RCCL called from the library, not torch.distributed) --
+    def gather_init(self, unique_id, rank, world, all_observations, all_rewards, all_terminals, all_truncations, counts=None):
+        """``unique_id``: the DRONE_GATHER_ID_BYTES bytes rank 0 got from ``gather_unique_id()``."""
+        idbuf = (C.c_ubyte * abi.GATHER_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        cnt = None
+        if counts is not None:
+            cnt = (C.c_int * world)(*[int(c) for c in counts])
+        self._gathered = (all_observations, all_rewards, all_terminals, all_truncations)  # keep alive
+        self._check(self._f["drone_vec_gather_init"](self._h, C.cast(idbuf, C.c_void_p), int(rank), int(world),
+                                                      C.cast(cnt, C.c_void_p) if cnt is not None else None,
+                                                      _ptr(all_observations), _ptr(all_rewards), _ptr(all_terminals), _ptr(all_truncations)))
+
+    def gather(self):
+        self._check(self._f["drone_vec_gather"](self._h))
+        return self._gathered
+
+    def gather_close(self):
+        self._f["drone_vec_gather_close"](self._h)
+        self._gathered = None
 
     def bind_actions(self, actions):
         self._check(self._f["drone_vec_bind_actions"](self._h, _ptr(actions)))

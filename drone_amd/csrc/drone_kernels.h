@@ -23,7 +23,7 @@ struct DeviceView {
     unsigned char* term; // [n]
     unsigned char* trunc;// [n]
     uint32_t* done_ids;  // [n] or null
-    uint32_t* done_count;// [2] ping-pong by gstep parity, or null
+    uint32_t* done_count;// [2] ping-pong per step launch, or null
 };
 
 #ifndef DRONE_BLOCK  // workgroup size (tuning knob; multiple of 64)
@@ -32,7 +32,8 @@ struct DeviceView {
 constexpr int kBlock = DRONE_BLOCK;
 
 hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s);
-hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s);
+// done_slot: which done_count slot this launch adds to (compact_done); the kernel zeroes the other one for the next step launch
+hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s);
 hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s);
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s);
 // partials: [grid][6] doubles; returns grid size via *grid_out. Clears the log planes.

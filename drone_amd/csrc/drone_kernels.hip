@@ -149,6 +149,7 @@ struct StepArgs {
     DeviceView v;
     uint32_t gstep;
     uint32_t flags_aligned;  // bit0: terminals 16-B aligned, bit1: truncations 16-B aligned
+    uint32_t done_slot;      // which of the two done-list counters this step launch adds to (the host alternates per STEP launch)
 #if !DRONE_PARAMS_IN_LDS
     KParams kp;              // constants by value: scalar loads from the kernarg segment
 #endif
@@ -337,10 +338,10 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
 
     if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
         const uint64_t m_done = __ballot(done);
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[(a.gstep + 1u) & 1u] = 0u;  // arm the next step's counter
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[a.done_slot ^ 1u] = 0u;  // arm the next step launch's counter
         if (m_done != 0) {  // wave-uniform
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.v.done_count + (a.gstep & 1u), (uint32_t)__popcll(m_done));
+            if (lane == 0) base = atomicAdd(a.v.done_count + a.done_slot, (uint32_t)__popcll(m_done));
             base = __shfl(base, 0);
             if (done) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
@@ -484,6 +485,7 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     StepArgs a;
     a.v = v;
     a.gstep = gstep;
+    a.done_slot = 0;
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
 #if !DRONE_PARAMS_IN_LDS
     a.kp = *v.kp_host;
@@ -503,8 +505,9 @@ hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, hipStream_t s) {
-    const StepArgs a = make_args(v, gstep);
+hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s) {
+    StepArgs a = make_args(v, gstep);
+    a.done_slot = done_slot & 1u;
     const dim3 g(grid_for(v.n)), b(kBlock);
     const bool compact = v.done_ids != nullptr;
     if (task == DRONE_TASK_HOVER) {

@@ -11,6 +11,7 @@
 // reference file:line cannot be cited — no source in /root/reference
 // (.gitmodules:1-3).
 #include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -18,6 +19,8 @@
 #include <cstring>
 #include <new>
 #include <vector>
+
+#include <rccl/rccl.h>  // types only: the library is dlopen'ed on first use (drone_vec_gather_init), never linked
 
 #include "drone_kernels.h"
 
@@ -84,13 +87,56 @@ struct DroneVec {
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
+    // done-id list (compact_done): the counter slot is keyed on the number of STEP launches, not on gstep, so a
+    // fused rollout (which advances gstep but builds no list) cannot desynchronise the ping-pong
+    uint32_t step_launches;
+    bool list_valid;     // the last path call was drone_vec_step
+    // sticky status: the first failure of any call on this handle (drone_vec_status)
+    int status;
+    char status_msg[512];
+    struct Gather* gather;  // host-boundary all-gather over RCCL (drone_vec_gather_init), or null
 };
 
 namespace {
 
-bool set_device(const DroneVec* v) {
-    HIP_TRY(hipSetDevice(v->device), return false);
-    return true;
+// Every entry point that takes a handle opens with one of these: clears the
+// calling thread's error text, switches to the handle's device and puts the
+// caller's device back on the way out (a process that drives several GPUs, or
+// torch with another current device, must not find its device changed by a
+// step()); a failure anywhere inside the call sticks to the handle
+// (drone_vec_status) because the path calls themselves return void.
+struct Entry {
+    DroneVec* v;
+    int prev = -1;
+    bool ok = false;
+    explicit Entry(const DroneVec* cv) : v(const_cast<DroneVec*>(cv)) {
+        g_err[0] = 0;
+        if (!v) { set_err("handle is NULL"); return; }
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != v->device) {
+            hipError_t e = hipSetDevice(v->device);
+            if (e != hipSuccess) { set_err("hipSetDevice(%d) failed: %s", v->device, hipGetErrorString(e)); return; }
+        }
+        ok = true;
+    }
+    ~Entry() {
+        if (v && g_err[0] && v->status == 0) {
+            v->status = 1;
+            snprintf(v->status_msg, sizeof(v->status_msg), "%s", g_err);
+        }
+        if (v && prev >= 0 && prev != v->device) (void)hipSetDevice(prev);
+    }
+    explicit operator bool() const { return ok; }
+};
+
+// Plane stride padding, in float4 elements (DRONE_PLANE_PAD, tuning experiments
+// only). With a power-of-two env count the planes sit exactly 2^k bytes apart;
+// the HBM address hash copes: pads of 16...65552 elements measure within +-0.7 %
+// of no pad at equal placement (profiles/r01_ab/ab14_pad.txt), so the default is 0.
+uint32_t plane_pad_elems() {
+    const char* e = getenv("DRONE_PLANE_PAD");
+    if (e && *e) return (uint32_t)strtoul(e, nullptr, 10);
+    return 0;
 }
 
 bool upload_params(DroneVec* v) {
@@ -111,6 +157,14 @@ bool validate(const DroneConfig* c, int num_envs) {
         if (A < 1 || A > 64 || (A & (A - 1))) { set_err("agents_per_env must be a power of two in [1, 64], got %d", A); return false; }
         if (num_envs % A || c->env_offset % (uint32_t)A) { set_err("num_envs and env_offset must be multiples of agents_per_env (%d)", A); return false; }
         if (!(c->proximity_radius > 0.0f)) { set_err("proximity_radius must be positive"); return false; }
+    }
+    {   // plane addressing in the kernels is 32-bit: kNumPlanes * stride must fit (DRONE_PLANE_PAD included)
+        const uint64_t n_pad = ((uint64_t)num_envs + kBlock - 1) / kBlock * kBlock;
+        if ((uint64_t)kNumPlanes * (n_pad + plane_pad_elems()) > 0xFFFFFFFFull) {
+            set_err("num_envs %d too large: %d planes x stride must fit 32-bit element indices (max about %llu envs per handle; shard further)",
+                    num_envs, (int)kNumPlanes, (unsigned long long)(0xFFFFFFFFull / kNumPlanes - kBlock));
+            return false;
+        }
     }
     if (c->buffer_kind != DRONE_BUFFERS_HOST && c->buffer_kind != DRONE_BUFFERS_DEVICE) { set_err("unknown buffer_kind %d", c->buffer_kind); return false; }
     if (c->substeps < 1 || c->horizon < 1) { set_err("substeps and horizon must be >= 1"); return false; }
@@ -141,16 +195,6 @@ bool device_to_host_outputs(DroneVec* v) {
     HIP_TRY(hipMemcpyAsync(v->u_trunc, v->d_trunc, n, hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
     return true;
-}
-
-// Plane stride padding, in float4 elements (DRONE_PLANE_PAD, tuning experiments
-// only). With a power-of-two env count the planes sit exactly 2^k bytes apart;
-// the HBM address hash copes: pads of 16...65552 elements measure within +-0.7 %
-// of no pad at equal placement (profiles/r01_ab/ab14_pad.txt), so the default is 0.
-uint32_t plane_pad_elems() {
-    const char* e = getenv("DRONE_PLANE_PAD");
-    if (e && *e) return (uint32_t)strtoul(e, nullptr, 10);
-    return 0;
 }
 
 // Host-buffer mode has two transports. Mirror: actions H2D, kernel on device
@@ -191,6 +235,103 @@ void try_register(DroneVec* v, int slot, void* p, size_t bytes) {
     v->registered[slot] = (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess);
     v->registered_ptr[slot] = p;
     if (!v->registered[slot]) (void)hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------
+// Host-boundary all-gather over RCCL (BASELINE.json north_star:
+// "RCCL gather of obs/rewards over xGMI only at the host boundary"). The env
+// path itself has no collective; this is the one exchange step, for a consumer
+// that wants every rank's observations / rewards / flags in one buffer.
+// librccl is dlopen'ed on first use so that single-GPU users never load it; in
+// a process where torch already mapped its librccl.so.1 the same copy is reused.
+// ---------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (r.lib) return &r;
+    if (tried) { set_err("librccl could not be loaded earlier in this process"); return nullptr; }
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { set_err("dlopen(librccl.so.1) failed: %s", dlerror()); return nullptr; }
+#define RCCL_SYM(field, name)                                                        \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));               \
+    if (!r.field) { set_err("librccl has no symbol %s", name); dlclose(r.lib); r.lib = nullptr; return nullptr; }
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RCCL_SYM(AllGather, "ncclAllGather")
+    RCCL_SYM(Broadcast, "ncclBroadcast")
+    RCCL_SYM(GroupStart, "ncclGroupStart")
+    RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    return &r;
+}
+
+#define RCCL_TRY(R, expr, onfail)                                                          \
+    do {                                                                                   \
+        ncclResult_t r_ = (expr);                                                          \
+        if (r_ != ncclSuccess) {                                                           \
+            set_err("%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(r_), __FILE__, __LINE__); \
+            onfail;                                                                        \
+        }                                                                                  \
+    } while (0)
+
+}  // namespace
+
+struct Gather {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    std::vector<size_t> counts, offsets;  // envs per rank, first global row of each rank
+    size_t total = 0;
+    bool equal = true;
+    // device-side global buffers: the caller's (device-buffer handles) or staging owned here (host-buffer handles)
+    float* g_obs = nullptr;
+    float* g_rew = nullptr;
+    unsigned char* g_term = nullptr;
+    unsigned char* g_trunc = nullptr;
+    bool own_staging = false;
+    // host-buffer handles: where the gathered batch is copied to after the collective
+    float* h_obs = nullptr;
+    float* h_rew = nullptr;
+    unsigned char* h_term = nullptr;
+    unsigned char* h_trunc = nullptr;
+};
+
+namespace {
+
+void gather_destroy(DroneVec* v) {
+    Gather* g = v->gather;
+    if (!g) return;
+    if (g->comm) {
+        Rccl* R = rccl();
+        if (R) (void)R->CommDestroy(g->comm);
+    }
+    if (g->own_staging) {
+        (void)hipFree(g->g_obs);
+        (void)hipFree(g->g_rew);
+        (void)hipFree(g->g_term);
+        (void)hipFree(g->g_trunc);
+    }
+    delete g;
+    v->gather = nullptr;
 }
 
 }  // namespace
@@ -263,7 +404,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->cfg = *cfg;
     v->seed = seed;
     v->n = num_envs;
-    v->n_pad = (uint32_t)((num_envs + kBlock - 1) / kBlock) * kBlock;
+    v->n_pad = (uint32_t)(((uint64_t)num_envs + kBlock - 1) / kBlock * kBlock);
     v->stride = v->n_pad + plane_pad_elems();
     v->device = cfg->device;
     v->host_buffers = cfg->buffer_kind == DRONE_BUFFERS_HOST;
@@ -333,33 +474,43 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
 }
 
 void drone_vec_reset(DroneVec* v, uint64_t seed) {
-    if (!v || !set_device(v)) return;
+    Entry in(v);
+    if (!in) return;
     v->seed = seed;
     v->gstep = 0;
+    v->step_launches = 0;  // the reset kernel zeroes both done-count slots
+    v->list_valid = false;
     if (!upload_params(v)) return;
     HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream), return);
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
 void drone_vec_step(DroneVec* v) {
-    if (!v || !set_device(v)) return;
+    Entry in(v);
+    if (!in) return;
     if (v->host_buffers && !host_to_device_actions(v)) return;
-    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->stream), return);
+    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream), return);
     v->gstep += 1;
+    v->step_launches += 1;
+    v->list_valid = true;
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
 void drone_vec_rollout(DroneVec* v, int horizon) {
-    if (!v || horizon <= 0 || !set_device(v)) return;
+    Entry in(v);
+    if (!in) return;
+    if (horizon <= 0) { set_err("rollout: horizon must be positive, got %d", horizon); return; }
     HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream), return);
     v->gstep += (uint32_t)horizon;
+    v->list_valid = false;  // the fused rollout builds no done-id list
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
 void drone_vec_log(DroneVec* v, DroneLog* out) {
     if (!out) return;
     memset(out, 0, sizeof(*out));
-    if (!v || !set_device(v)) return;
+    Entry in(v);
+    if (!in) return;
     int grid = 0;
     HIP_TRY(launch_log_reduce(v->dv, v->d_partials, kLogMaxGrid, &grid, v->stream), return);
     HIP_TRY(hipMemcpyAsync(v->h_partials, v->d_partials, sizeof(double) * 6 * grid, hipMemcpyDeviceToHost, v->stream), return);
@@ -380,8 +531,11 @@ void drone_vec_log(DroneVec* v, DroneLog* out) {
 
 void drone_vec_close(DroneVec* v) {
     if (!v) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
+    gather_destroy(v);
     for (int i = 0; i < 5; i++)
         if (v->registered[i]) (void)hipHostUnregister(v->registered_ptr[i]);
     (void)hipFree(v->dv.planes);
@@ -398,13 +552,15 @@ void drone_vec_close(DroneVec* v) {
     if (v->ev0) (void)hipEventDestroy(v->ev0);
     if (v->ev1) (void)hipEventDestroy(v->ev1);
     if (v->own_stream && v->stream) (void)hipStreamDestroy(v->stream);
+    if (prev >= 0 && prev != v->device) (void)hipSetDevice(prev);
     delete v;
 }
 
 int drone_vec_set_stream(DroneVec* v, void* hip_stream) {
     if (!v) return -1;
     if ((hipStream_t)hip_stream == v->stream && !v->own_stream) return 0;  // cheap to call every step
-    if (!set_device(v)) return -1;
+    Entry in(v);
+    if (!in) return -1;
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     if (v->own_stream && v->stream) (void)hipStreamDestroy(v->stream);
     v->stream = (hipStream_t)hip_stream;
@@ -413,13 +569,15 @@ int drone_vec_set_stream(DroneVec* v, void* hip_stream) {
 }
 
 int drone_vec_sync(DroneVec* v) {
-    if (!v) return -1;
+    Entry in(v);
+    if (!in) return -1;
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     return 0;
 }
 
 int drone_vec_bind_actions(DroneVec* v, float* actions) {
-    if (!v || !actions) return -1;
+    g_err[0] = 0;
+    if (!v || !actions) { set_err("bind_actions: NULL argument"); return -1; }
     if (v->host_buffers) {
         if (v->zero_copy && actions != v->u_act) leave_zero_copy(v);  // an unregistered buffer: back to the mirror transport
         v->u_act = actions;  // copied (pageable unless the caller pinned it) at the next step
@@ -432,6 +590,7 @@ int drone_vec_bind_actions(DroneVec* v, float* actions) {
 }
 
 int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, unsigned char* terminals, unsigned char* truncations) {
+    g_err[0] = 0;
     if (!v || !observations || !rewards || !terminals || !truncations) { set_err("bind_outputs: NULL argument"); return -1; }
     if (!v->host_buffers) {
         if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
@@ -449,8 +608,9 @@ int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, uns
 }
 
 int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep) {
-    if (!v || !actions) return -1;
-    if (!set_device(v)) return -1;
+    Entry in(v);
+    if (!in) return -1;
+    if (!actions) { set_err("fill_random_actions: NULL buffer"); return -1; }
     if (v->host_buffers) {
         // generate on the device into the action mirror, then hand the host its copy
         HIP_TRY(launch_fill_actions(v->dv, v->d_act, gstep, v->stream), return -1);
@@ -464,12 +624,29 @@ int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep) {
 }
 
 uint32_t drone_vec_gstep(const DroneVec* v) { return v ? v->gstep : 0u; }
+
+int drone_vec_set_gstep(DroneVec* v, uint32_t gstep) {
+    Entry in(v);
+    if (!in) return -1;
+    v->gstep = gstep;
+    v->list_valid = false;
+    return 0;
+}
+
+int drone_vec_status(const DroneVec* v) { return v ? v->status : -1; }
+const char* drone_vec_status_message(const DroneVec* v) { return v ? v->status_msg : "handle is NULL"; }
+void drone_vec_clear_status(DroneVec* v) {
+    if (!v) return;
+    v->status = 0;
+    v->status_msg[0] = 0;
+}
 int drone_vec_num_envs(const DroneVec* v) { return v ? v->n : 0; }
 
 // ---- AoS import / export (tests, checkpoints): plain copies + host repack ----
 int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) {
-    if (!v || !rows || first < 0 || count < 0 || first + count > v->n) { set_err("get_state: bad range"); return -1; }
-    if (!set_device(v)) return -1;
+    Entry in(v);
+    if (!in) return -1;
+    if (!rows || first < 0 || count < 0 || first + count > v->n) { set_err("get_state: bad range"); return -1; }
     std::vector<float4> tmp((size_t)kNumPlanes * count);
     for (int p = 0; p < kNumPlanes; p++)
         HIP_TRY(hipMemcpyAsync(tmp.data() + (size_t)p * count, v->dv.planes + (size_t)p * v->stride + first, sizeof(float4) * count, hipMemcpyDeviceToHost, v->stream), return -1);
@@ -494,8 +671,9 @@ int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) 
 }
 
 int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int count) {
-    if (!v || !rows || first < 0 || count < 0 || first + count > v->n) { set_err("set_state: bad range"); return -1; }
-    if (!set_device(v)) return -1;
+    Entry in(v);
+    if (!in) return -1;
+    if (!rows || first < 0 || count < 0 || first + count > v->n) { set_err("set_state: bad range"); return -1; }
     std::vector<float4> tmp((size_t)kNumPlanes * count);
     auto f = [](uint32_t x) { float y; memcpy(&y, &x, 4); return y; };
     for (int i = 0; i < count; i++) {
@@ -517,11 +695,13 @@ int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int c
 }
 
 int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap) {
-    if (!v || !v->dv.done_ids) { set_err("done list not enabled (compact_done=0)"); return -1; }
-    if (v->gstep == 0) return 0;
-    if (!set_device(v)) return -1;
+    Entry in(v);
+    if (!in) return -1;
+    if (!v->dv.done_ids) { set_err("done list not enabled (compact_done=0)"); return -1; }
+    if (!v->list_valid || v->step_launches == 0) return 0;  // after reset / after a fused rollout there is no list
     uint32_t cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, v->dv.done_count + ((v->gstep - 1u) & 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, v->stream), return -1);
+    HIP_TRY(hipMemcpyAsync(&cnt, v->dv.done_count + ((v->step_launches - 1u) & 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, v->stream), return -1);
+    if (cnt > (uint32_t)v->n) { set_err("done list count %u exceeds num_envs %d (corrupt counter)", cnt, v->n); return -1; }
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     const int take = (int)cnt < cap ? (int)cnt : cap;
     if (ids && take > 0) {
@@ -532,17 +712,132 @@ int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap) {
 }
 
 int drone_vec_timer_start(DroneVec* v) {
-    if (!v) return -1;
+    Entry in(v);
+    if (!in) return -1;
     HIP_TRY(hipEventRecord(v->ev0, v->stream), return -1);
     return 0;
 }
 
 int drone_vec_timer_stop(DroneVec* v, float* elapsed_ms) {
-    if (!v || !elapsed_ms) return -1;
+    Entry in(v);
+    if (!in || !elapsed_ms) return -1;
     HIP_TRY(hipEventRecord(v->ev1, v->stream), return -1);
     HIP_TRY(hipEventSynchronize(v->ev1), return -1);
     HIP_TRY(hipEventElapsedTime(elapsed_ms, v->ev0, v->ev1), return -1);
     return 0;
+}
+
+// ---- host-boundary all-gather (RCCL) ----
+int drone_gather_unique_id(unsigned char* id) {
+    g_err[0] = 0;
+    if (!id) { set_err("gather_unique_id: NULL buffer"); return -1; }
+    Rccl* R = rccl();
+    if (!R) return -1;
+    static_assert(sizeof(ncclUniqueId) == DRONE_GATHER_ID_BYTES, "DRONE_GATHER_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId u;
+    RCCL_TRY(R, R->GetUniqueId(&u), return -1);
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts,
+                          float* all_observations, float* all_rewards, unsigned char* all_terminals, unsigned char* all_truncations) {
+    Entry in(v);
+    if (!in) return -1;
+    if (v->gather) { set_err("gather already initialised on this handle"); return -1; }
+    if (!id || world < 1 || rank < 0 || rank >= world) { set_err("gather_init: bad id / rank %d / world %d", rank, world); return -1; }
+    if (!all_observations || !all_rewards || !all_terminals || !all_truncations) { set_err("gather_init: NULL global buffer"); return -1; }
+    Rccl* R = rccl();
+    if (!R) return -1;
+    Gather* g = new (std::nothrow) Gather();
+    if (!g) { set_err("out of memory"); return -1; }
+    v->gather = g;
+    g->rank = rank;
+    g->world = world;
+    g->counts.resize(world);
+    g->offsets.resize(world);
+    for (int r = 0; r < world; r++) {
+        const int c = counts ? counts[r] : v->n;
+        if (c <= 0) { set_err("gather_init: counts[%d] = %d", r, c); gather_destroy(v); return -1; }
+        g->counts[r] = (size_t)c;
+        g->offsets[r] = g->total;
+        g->total += (size_t)c;
+        if (c != v->n) g->equal = false;
+    }
+    if (getenv("DRONE_GATHER_FORCE_V")) g->equal = false;  // tests: take the all-gather-v branch even with equal shards
+    if (g->counts[rank] != (size_t)v->n) { set_err("gather_init: counts[rank] = %zu but this handle has %d envs", g->counts[rank], v->n); gather_destroy(v); return -1; }
+    const size_t od = (size_t)drone_obs_dim(v->cfg.task);
+    if (v->host_buffers) {
+        // the collective reads device memory: step into the device mirrors, gather into staging, copy the batch out
+        if (v->zero_copy) leave_zero_copy(v);
+        g->own_staging = true;
+        g->h_obs = all_observations; g->h_rew = all_rewards; g->h_term = all_terminals; g->h_trunc = all_truncations;
+#define G_TRY(expr) HIP_TRY(expr, { gather_destroy(v); return -1; })
+        G_TRY(hipMalloc((void**)&g->g_obs, g->total * od * sizeof(float)));
+        G_TRY(hipMalloc((void**)&g->g_rew, g->total * sizeof(float)));
+        G_TRY(hipMalloc((void**)&g->g_term, g->total));
+        G_TRY(hipMalloc((void**)&g->g_trunc, g->total));
+#undef G_TRY
+    } else {
+        if (reinterpret_cast<uintptr_t>(all_observations) & 15u) { set_err("gather_init: global observations must be 16-byte aligned"); gather_destroy(v); return -1; }
+        g->g_obs = all_observations; g->g_rew = all_rewards; g->g_term = all_terminals; g->g_trunc = all_truncations;
+    }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    RCCL_TRY(R, R->CommInitRank(&g->comm, world, u, rank), { g->comm = nullptr; gather_destroy(v); return -1; });
+    return 0;
+}
+
+int drone_vec_gather(DroneVec* v) {
+    Entry in(v);
+    if (!in) return -1;
+    Gather* g = v->gather;
+    if (!g) { set_err("gather not initialised (drone_vec_gather_init)"); return -1; }
+    Rccl* R = rccl();
+    if (!R) return -1;
+    const size_t od = (size_t)drone_obs_dim(v->cfg.task);
+    const size_t n = (size_t)v->n;
+    // sources: whatever the kernels currently write (the caller's device buffers or the mirrors)
+    const float* s_obs = v->dv.obs;
+    const float* s_rew = v->dv.rew;
+    const unsigned char* s_term = v->dv.term;
+    const unsigned char* s_trunc = v->dv.trunc;
+    // one grouped launch for the four buffers; a send buffer that already is this rank's slice of the
+    // global buffer makes the collective in-place
+    RCCL_TRY(R, R->GroupStart(), return -1);
+    bool ok = true;
+    if (g->equal) {
+        ok = ok && R->AllGather(s_obs, g->g_obs, n * od, ncclFloat, g->comm, v->stream) == ncclSuccess;
+        ok = ok && R->AllGather(s_rew, g->g_rew, n, ncclFloat, g->comm, v->stream) == ncclSuccess;
+        ok = ok && R->AllGather(s_term, g->g_term, n, ncclUint8, g->comm, v->stream) == ncclSuccess;
+        ok = ok && R->AllGather(s_trunc, g->g_trunc, n, ncclUint8, g->comm, v->stream) == ncclSuccess;
+    } else {  // ragged shards: one broadcast per rank into its rows (an all-gather-v)
+        for (int r = 0; r < g->world && ok; r++) {
+            const size_t c = g->counts[r], o = g->offsets[r];
+            const bool me = r == g->rank;
+            ok = ok && R->Broadcast(me ? (const void*)s_obs : (const void*)(g->g_obs + o * od), g->g_obs + o * od, c * od, ncclFloat, r, g->comm, v->stream) == ncclSuccess;
+            ok = ok && R->Broadcast(me ? (const void*)s_rew : (const void*)(g->g_rew + o), g->g_rew + o, c, ncclFloat, r, g->comm, v->stream) == ncclSuccess;
+            ok = ok && R->Broadcast(me ? (const void*)s_term : (const void*)(g->g_term + o), g->g_term + o, c, ncclUint8, r, g->comm, v->stream) == ncclSuccess;
+            ok = ok && R->Broadcast(me ? (const void*)s_trunc : (const void*)(g->g_trunc + o), g->g_trunc + o, c, ncclUint8, r, g->comm, v->stream) == ncclSuccess;
+        }
+    }
+    RCCL_TRY(R, R->GroupEnd(), return -1);
+    if (!ok) { set_err("an RCCL collective of drone_vec_gather failed to enqueue"); return -1; }
+    if (v->host_buffers) {
+        HIP_TRY(hipMemcpyAsync(g->h_obs, g->g_obs, g->total * od * sizeof(float), hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipMemcpyAsync(g->h_rew, g->g_rew, g->total * sizeof(float), hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipMemcpyAsync(g->h_term, g->g_term, g->total, hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipMemcpyAsync(g->h_trunc, g->g_trunc, g->total, hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    }
+    return 0;
+}
+
+void drone_vec_gather_close(DroneVec* v) {
+    Entry in(v);
+    if (!in) return;
+    if (v->stream) (void)hipStreamSynchronize(v->stream);
+    gather_destroy(v);
 }
 
 }  // extern "C"

@@ -52,6 +52,8 @@ class BoundaryGather:
                 "term": torch.zeros(self.max_count, dtype=torch.uint8, device=device),
                 "trunc": torch.zeros(self.max_count, dtype=torch.uint8, device=device),
             }
+            # rows of the padded gather that are real envs, in global env order (built once, not per step)
+            self._keep = torch.cat([torch.arange(r * self.max_count, r * self.max_count + c, device=device) for r, c in enumerate(self.counts)])
 
     def __call__(self, obs, rew, term, trunc):
         """Gather this rank's outputs; returns global (obs, rew, term, trunc) in env-id order."""
@@ -65,7 +67,7 @@ class BoundaryGather:
         for k in srcs:
             self._pad[k][:mine].copy_(srcs[k])
             dist.all_gather_into_tensor(dsts[k], self._pad[k], group=self.group)
-        keep = torch.cat([torch.arange(r * self.max_count, r * self.max_count + c, device=self.obs.device) for r, c in enumerate(self.counts)])
+        keep = self._keep
         return self.obs[keep], self.rew[keep], self.term[keep], self.trunc[keep]
 
 
@@ -104,6 +106,8 @@ class PipelinedGather:
             self.vec.step()
             return self.gathers[i](*outs), None
         main = torch.cuda.current_stream(outs[0].device)
+        if hasattr(self.vec, "use_torch_stream"):
+            self.vec.use_torch_stream()  # launch on the stream the events below are recorded on (a no-op while it is unchanged)
         main.wait_event(self.done[i])  # the gather that last read this set (two steps ago) has finished
         self.vec.bind_outputs(*outs)
         self.vec.step()

@@ -5,18 +5,41 @@
  * side stays C calling HIP through a thin C-ABI".) No HIP headers here: the
  * device is entirely behind the C-ABI.
  *
- *   drone_host [--envs N] [--steps K] [--task 0|1] [--rollout T] [--seed S]
+ *   drone_host [--envs N] [--steps K] [--task 0..3] [--rollout T] [--seed S] [--crc 1]
  *
  * Prints env-steps/s for (a) per-step calls with host buffers — every step
  * pays H2D actions + D2H observations/rewards/flags over PCIe — and (b) the
  * fused rollout, which crosses PCIe once per T steps.
+ * With --crc 1 it instead runs K random-policy steps from reset and prints a
+ * CRC-32 (zlib polynomial) chained over every step's observations, rewards,
+ * terminals and truncations: tests/test_c_host.py compares it with the CPU
+ * oracle's, so this pure-C caller is parity-checked too.
  */
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
 #include "drone_vec.h"
+
+/* CRC-32 (IEEE 802.3, reflected, as zlib.crc32): crc of `buf` continuing from `crc` */
+static uint32_t crc32_update(uint32_t crc, const void* buf, size_t len) {
+    static uint32_t table[256];
+    static int ready = 0;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = 1;
+    }
+    const unsigned char* p = (const unsigned char*)buf;
+    crc = ~crc;
+    for (size_t i = 0; i < len; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
 
 static double now_s(void) {
     struct timespec ts;
@@ -25,7 +48,7 @@ static double now_s(void) {
 }
 
 int main(int argc, char** argv) {
-    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128;
+    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0;
     unsigned long long seed = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--envs")) envs = atoi(argv[i + 1]);
@@ -33,9 +56,16 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--task")) task = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--rollout")) rollout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], NULL, 10);
+        else if (!strcmp(argv[i], "--crc")) crc_mode = atoi(argv[i + 1]);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
-    float* obs = (float*)malloc(sizeof(float) * (size_t)envs * DRONE_OBS_DIM);
+    if (task != DRONE_TASK_HOVER && task != DRONE_TASK_WAYPOINT && task != DRONE_TASK_SWARM && task != DRONE_TASK_RACE) {
+        fprintf(stderr, "unknown task %d (0 hover, 1 waypoint, 2 swarm, 3 race)\n", task);
+        return 2;
+    }
+    if (envs <= 0 || steps <= 0 || rollout <= 0) { fprintf(stderr, "--envs, --steps and --rollout must be positive\n"); return 2; }
+    const size_t obs_dim = (size_t)drone_obs_dim(task); /* 20, or 24 for the swarm and race tasks */
+    float* obs = (float*)malloc(sizeof(float) * (size_t)envs * obs_dim);
     float* act = (float*)malloc(sizeof(float) * (size_t)envs * DRONE_ACT_DIM);
     float* rew = (float*)malloc(sizeof(float) * (size_t)envs);
     unsigned char* term = (unsigned char*)malloc((size_t)envs);
@@ -48,6 +78,27 @@ int main(int argc, char** argv) {
     DroneVec* v = drone_vec_init(obs, act, rew, term, trunc, envs, seed, &cfg);
     if (!v) { fprintf(stderr, "drone_vec_init failed: %s\n", drone_last_error()); return 1; }
     drone_vec_reset(v, seed);
+    if (drone_vec_status(v)) { fprintf(stderr, "drone_vec_reset failed: %s\n", drone_vec_status_message(v)); return 1; }
+
+    if (crc_mode) {
+        uint32_t crc = 0;
+        crc = crc32_update(crc, obs, sizeof(float) * (size_t)envs * obs_dim); /* the reset observations */
+        for (int t = 0; t < steps; t++) {
+            drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
+            drone_vec_step(v);
+            crc = crc32_update(crc, obs, sizeof(float) * (size_t)envs * obs_dim);
+            crc = crc32_update(crc, rew, sizeof(float) * (size_t)envs);
+            crc = crc32_update(crc, term, (size_t)envs);
+            crc = crc32_update(crc, trunc, (size_t)envs);
+        }
+        if (drone_vec_status(v)) { fprintf(stderr, "step failed: %s\n", drone_vec_status_message(v)); return 1; }
+        DroneLog lg;
+        drone_vec_log(v, &lg);
+        printf("{\"mode\": \"crc\", \"task\": %d, \"envs\": %d, \"steps\": %d, \"crc32\": %u, \"episodes\": %.0f}\n", task, envs, steps, crc, lg.n);
+        drone_vec_close(v);
+        free(obs); free(act); free(rew); free(term); free(trunc);
+        return 0;
+    }
 
     /* (a) per-step, host buffers: the random policy stands in for the caller's policy */
     for (int t = 0; t < 10; t++) { drone_vec_fill_random_actions(v, act, drone_vec_gstep(v)); drone_vec_step(v); }
@@ -75,6 +126,7 @@ int main(int argc, char** argv) {
     drone_vec_log(v, &log);
     printf("{\"log\": {\"n\": %.0f, \"episode_return\": %.5g, \"episode_length\": %.5g, \"score\": %.5g, \"oob\": %.5g}, \"sampled_dones\": %ld}\n",
            log.n, log.episode_return, log.episode_length, log.score, log.oob, dones);
+    if (drone_vec_status(v)) { fprintf(stderr, "a call on the handle failed: %s\n", drone_vec_status_message(v)); return 1; }
     drone_vec_close(v);
     free(obs); free(act); free(rew); free(term); free(trunc);
     return 0;

@@ -1,0 +1,207 @@
+/*
+ * drone_host_mp.c — plain-C multi-GPU host: one PROCESS per GPU, forked before
+ * anything touches HIP, each driving its contiguous shard of the envs through
+ * include/drone_vec.h, with the north-star's one exchange step — the RCCL
+ * all-gather of observations / rewards / flags at the host boundary — reached
+ * from C through drone_vec_gather (BASELINE.json north_star:
+ * "host side stays C calling HIP through a thin C-ABI"). No HIP or RCCL headers
+ * here: both stay behind the C-ABI.
+ *
+ *   drone_host_mp [--gpus G] [--envs TOTAL] [--steps K] [--task 0..3] [--seed S]
+ *                 [--gather 0|1] [--rollout T] [--crc 1]
+ *
+ * Rank r takes envs [offset_r, offset_r + count_r) (the first TOTAL % G ranks get
+ * one more) on device r. The RCCL unique id is made by rank 0 AFTER the fork and
+ * handed to the other ranks through an anonymous shared mapping created before
+ * the fork — the bootstrap needs nothing but plain C. Every rank keeps the whole
+ * batch in host memory (its local buffers are its slice of the global ones).
+ * Rank 0 prints one JSON line; with --crc 1 the CRC-32 chained over every step's
+ * gathered batch, which tests/test_c_host.py compares with the CPU oracle's.
+ * --rollout T: fused T-step rollouts with the gather once per horizon (configs[4]).
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "drone_vec.h"
+
+typedef struct Shared {
+    volatile int id_ready;
+    volatile int failed;
+    unsigned char id[DRONE_GATHER_ID_BYTES];
+    volatile int arrived[2]; /* sense-reversing barrier over the ranks */
+    volatile int sense;
+    double rank_seconds[64];
+} Shared;
+
+static uint32_t crc32_update(uint32_t crc, const void* buf, size_t len) {
+    static uint32_t table[256];
+    static int ready = 0;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = 1;
+    }
+    const unsigned char* p = (const unsigned char*)buf;
+    crc = ~crc;
+    for (size_t i = 0; i < len; i++) crc = table[(crc ^ p[i]) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void barrier(Shared* sh, int world, int* local_sense) {
+    *local_sense = !*local_sense;
+    const int slot = *local_sense;
+    if (__sync_add_and_fetch(&sh->arrived[slot], 1) == world) {
+        sh->arrived[slot] = 0;
+        __sync_synchronize();
+        sh->sense = *local_sense;
+    } else {
+        while (sh->sense != *local_sense && !sh->failed) usleep(50);
+    }
+}
+
+typedef struct Opts {
+    int gpus, total, steps, task, gather, rollout, crc;
+    unsigned long long seed;
+} Opts;
+
+static int run_rank(const Opts* o, int rank, Shared* sh) {
+    const int world = o->gpus;
+    int counts[64], offsets[64];
+    for (int r = 0, off = 0; r < world; r++) {
+        counts[r] = o->total / world + (r < o->total % world ? 1 : 0);
+        offsets[r] = off;
+        off += counts[r];
+    }
+    const int n = counts[rank];
+    const size_t od = (size_t)drone_obs_dim(o->task), total = (size_t)o->total;
+    /* the whole batch in host memory on every rank; the local buffers are this rank's slice of it */
+    float* all_obs = (float*)malloc(sizeof(float) * total * od);
+    float* all_rew = (float*)malloc(sizeof(float) * total);
+    unsigned char* all_term = (unsigned char*)malloc(total);
+    unsigned char* all_trunc = (unsigned char*)malloc(total);
+    float* act = (float*)malloc(sizeof(float) * (size_t)n * DRONE_ACT_DIM);
+    if (!all_obs || !all_rew || !all_term || !all_trunc || !act) { fprintf(stderr, "rank %d: out of memory\n", rank); return 1; }
+    memset(all_obs, 0, sizeof(float) * total * od);
+
+    DroneConfig cfg;
+    drone_config_default(&cfg, o->task);
+    cfg.buffer_kind = DRONE_BUFFERS_HOST;
+    cfg.device = rank; /* one process per GPU */
+    cfg.env_offset = (uint32_t)offsets[rank];
+    DroneVec* v = drone_vec_init(all_obs + (size_t)offsets[rank] * od, act, all_rew + offsets[rank], all_term + offsets[rank],
+                                 all_trunc + offsets[rank], n, o->seed, &cfg);
+    if (!v) { fprintf(stderr, "rank %d: drone_vec_init failed: %s\n", rank, drone_last_error()); return 1; }
+
+    if (o->gather) {
+        if (rank == 0) {
+            if (drone_gather_unique_id(sh->id) != 0) { fprintf(stderr, "rank 0: %s\n", drone_last_error()); return 1; }
+            __sync_synchronize();
+            sh->id_ready = 1;
+        } else {
+            while (!sh->id_ready && !sh->failed) usleep(100);
+            if (sh->failed) return 1;
+        }
+        unsigned char id[DRONE_GATHER_ID_BYTES];
+        memcpy(id, (const void*)sh->id, sizeof(id));
+        if (drone_vec_gather_init(v, id, rank, world, counts, all_obs, all_rew, all_term, all_trunc) != 0) {
+            fprintf(stderr, "rank %d: drone_vec_gather_init failed: %s\n", rank, drone_last_error());
+            return 1;
+        }
+    }
+
+    int sense = 0;
+    drone_vec_reset(v, o->seed);
+    if (o->gather && drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
+    uint32_t crc = 0;
+    if (o->crc) crc = crc32_update(crc, all_obs, sizeof(float) * total * od);
+    const int launches = o->rollout > 0 ? (o->steps + o->rollout - 1) / o->rollout : o->steps;
+    barrier(sh, world, &sense);
+    const double t0 = now_s();
+    for (int t = 0; t < launches; t++) {
+        if (o->rollout > 0) {
+            drone_vec_rollout(v, o->rollout);
+        } else {
+            drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
+            drone_vec_step(v);
+        }
+        if (o->gather && drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
+        if (o->crc) {
+            crc = crc32_update(crc, all_obs, sizeof(float) * total * od);
+            crc = crc32_update(crc, all_rew, sizeof(float) * total);
+            crc = crc32_update(crc, all_term, total);
+            crc = crc32_update(crc, all_trunc, total);
+        }
+    }
+    sh->rank_seconds[rank] = now_s() - t0;
+    if (drone_vec_status(v)) { fprintf(stderr, "rank %d: %s\n", rank, drone_vec_status_message(v)); return 1; }
+    barrier(sh, world, &sense);
+    if (rank == 0) {
+        double el = 0;
+        for (int r = 0; r < world; r++) el = sh->rank_seconds[r] > el ? sh->rank_seconds[r] : el;
+        const double env_steps = (double)o->total * (o->rollout > 0 ? (double)o->rollout : 1.0) * launches;
+        printf("{\"mode\": \"%s%s\", \"gpus\": %d, \"task\": %d, \"envs\": %d, \"launches\": %d, \"horizon\": %d, \"env_steps_per_s\": %.4g, "
+               "\"ms_per_launch\": %.4f, \"crc32\": %u}\n",
+               o->rollout > 0 ? "fused rollout" : "per-step", o->gather ? " + RCCL all-gather to every rank's host batch" : " (no gather)", world, o->task,
+               o->total, launches, o->rollout, env_steps / el, el * 1e3 / launches, crc);
+        fflush(stdout);
+    }
+    if (o->gather) drone_vec_gather_close(v);
+    drone_vec_close(v);
+    free(all_obs); free(all_rew); free(all_term); free(all_trunc); free(act);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0ull};
+    for (int i = 1; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "--gpus")) o.gpus = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--envs")) o.total = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--steps")) o.steps = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--task")) o.task = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--gather")) o.gather = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--rollout")) o.rollout = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--crc")) o.crc = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--seed")) o.seed = strtoull(argv[i + 1], NULL, 10);
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    if (o.gpus < 1 || o.gpus > 64 || o.total < o.gpus || o.steps < 1 || o.rollout < 0) { fprintf(stderr, "bad --gpus / --envs / --steps / --rollout\n"); return 2; }
+    if (o.task < 0 || o.task > 3) { fprintf(stderr, "unknown task %d\n", o.task); return 2; }
+    if (o.task == DRONE_TASK_SWARM && (o.total % (8 * o.gpus))) { fprintf(stderr, "swarm task: --envs must be a multiple of 8 x --gpus\n"); return 2; }
+
+    /* shared page + fork BEFORE any HIP call: a forked child of a process that initialised the GPU is not usable */
+    Shared* sh = (Shared*)mmap(NULL, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (sh == MAP_FAILED) { perror("mmap"); return 1; }
+    memset(sh, 0, sizeof(*sh));
+    pid_t pids[64];
+    for (int r = 0; r < o.gpus; r++) {
+        pids[r] = fork();
+        if (pids[r] < 0) { perror("fork"); sh->failed = 1; return 1; }
+        if (pids[r] == 0) {
+            const int rc = run_rank(&o, r, sh);
+            if (rc) sh->failed = 1;
+            _exit(rc);
+        }
+    }
+    int rc = 0;
+    for (int r = 0; r < o.gpus; r++) {
+        int st = 0;
+        waitpid(pids[r], &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st)) { rc = 1; sh->failed = 1; }
+    }
+    return rc;
+}

@@ -137,14 +137,54 @@ int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep);
 uint32_t drone_vec_gstep(const DroneVec* v);
 int drone_vec_num_envs(const DroneVec* v);
 
+/* Restore the vec-level step counter (checkpoints): wind gusts and the random
+ * policy are keyed on it (SPEC.md §2), so a run restored with set_state +
+ * set_gstep continues bit for bit like the uninterrupted one. */
+int drone_vec_set_gstep(DroneVec* v, uint32_t gstep);
+
+/* Sticky status of the handle. reset / step / rollout / log return void (the
+ * PufferLib convention), so a failed launch or copy would otherwise go
+ * unnoticed: the FIRST failure of any call on the handle is kept here until
+ * cleared. 0 = every call so far succeeded. */
+int drone_vec_status(const DroneVec* v);
+const char* drone_vec_status_message(const DroneVec* v);
+void drone_vec_clear_status(DroneVec* v);
+
 /* Copy envs [first, first+count) to / from AoS rows (host memory). */
 int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count);
 int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int count);
 
 /* compact_done=1 only: ids (local) of the envs that finished in the last
- * drone_vec_step (not drone_vec_rollout, which does not build the list),
- * unordered; returns their count (or -1). Copies at most `cap` ids. */
+ * drone_vec_step, unordered; returns their count (or -1). Copies at most `cap`
+ * ids. Returns 0 when the last path call was drone_vec_reset or
+ * drone_vec_rollout (the fused rollout builds no list). */
 int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap);
+
+/* ---- multi-GPU: the host-boundary exchange ----
+ * Envs shard over GPUs with no collective on the env path (one process and one
+ * handle per GPU, cfg.env_offset = first global id). A consumer that wants the
+ * whole batch in one place calls drone_vec_gather after a step / rollout: an
+ * RCCL all-gather (xGMI) of observations, rewards, terminals, truncations of
+ * every rank into global buffers in global-env order, enqueued on the handle's
+ * stream. librccl is dlopen'ed on first use; nothing here needs it otherwise.
+ *
+ * Bootstrap, plain C: ONE rank calls drone_gather_unique_id and ships the
+ * DRONE_GATHER_ID_BYTES bytes to the others by any means (pipe, shared
+ * memory, MPI, a file); every rank then calls drone_vec_gather_init (collective).
+ *   counts: envs per rank [world], or NULL when every rank has num_envs envs.
+ *   all_*:  global buffers [sum(counts)] rows, same kind as the handle's
+ *           buffers. Device kind: written asynchronously on the stream; a local
+ *           buffer that IS this rank's slice of the global one makes the
+ *           collective in-place. Host kind: the collective runs on device
+ *           staging, the batch is then copied to these host buffers and the
+ *           call returns after the copy (steps use the mirror transport). */
+#define DRONE_GATHER_ID_BYTES 128
+int drone_gather_unique_id(unsigned char* id);
+int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts,
+                          float* all_observations, float* all_rewards,
+                          unsigned char* all_terminals, unsigned char* all_truncations);
+int drone_vec_gather(DroneVec* v);
+void drone_vec_gather_close(DroneVec* v);
 
 /* HIP-event timer on the handle's stream: start, ..launches.., stop → ms. */
 int drone_vec_timer_start(DroneVec* v);

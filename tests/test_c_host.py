@@ -1,19 +1,42 @@
-"""The plain-C host program (host/drone_host.c): builds against the C-ABI with
-gcc alone, fails loudly without a GPU, runs on one."""
+"""The plain-C host programs (host/drone_host.c, host/drone_host_mp.c): build
+against the C-ABI with gcc alone, fail loudly without a GPU, and on a GPU produce
+the oracle's outputs — compared through a CRC-32 chained over every step's
+observations / rewards / terminals / truncations, for all four tasks."""
 import json
 import os
 import subprocess
+import zlib
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "host", "drone_host")
+EXE_MP = os.path.join(ROOT, "host", "drone_host_mp")
 
 
 @pytest.fixture(scope="module")
 def exe(hip):
     subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "-B"], check=True, capture_output=True)
     return EXE
+
+
+def oracle_crc(oracle, task, envs, steps, seed, rollout=0):
+    """What the C hosts print with --crc 1, from the CPU oracle."""
+    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=4)
+    o.reset(seed)
+    crc = zlib.crc32(o.observations.tobytes())
+    launches = steps if not rollout else (steps + rollout - 1) // rollout
+    for _ in range(launches):
+        if rollout:
+            o.rollout(rollout)
+        else:
+            o.fill_random_actions()
+            o.step()
+        for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+            crc = zlib.crc32(buf.tobytes(), crc)
+    n = o.log()["n"]
+    o.close()
+    return crc, n
 
 
 def test_c_host_builds_and_refuses_without_gpu(exe):
@@ -23,6 +46,15 @@ def test_c_host_builds_and_refuses_without_gpu(exe):
         pytest.skip("GPU present")
     r = subprocess.run([exe, "--envs", "16", "--steps", "1"], capture_output=True, text=True)
     assert r.returncode == 1 and "drone_vec_init failed" in r.stderr
+    r = subprocess.run([EXE_MP, "--envs", "16", "--steps", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "drone_vec_init failed" in r.stderr
+
+
+def test_c_host_rejects_unknown_task(exe):
+    r = subprocess.run([exe, "--task", "4"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unknown task" in r.stderr
+    r = subprocess.run([EXE_MP, "--task", "9"], capture_output=True, text=True)
+    assert r.returncode == 2 and "unknown task" in r.stderr
 
 
 @pytest.mark.gpu
@@ -32,3 +64,35 @@ def test_c_host_runs(exe):
     lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
     assert lines[0]["env_steps_per_s"] > 0 and lines[1]["env_steps_per_s"] > 0
     assert lines[2]["log"]["n"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", [0, 1, 2, 3])
+def test_c_host_crc_matches_oracle(exe, oracle, task):
+    """24-float rows for tasks 2 and 3 (the round-1 host under-allocated them)."""
+    envs, steps, seed = 4096, 300, 5
+    r = subprocess.run([exe, "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed), "--crc", "1"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    want, n = oracle_crc(oracle, task, envs, steps, seed)
+    assert got["crc32"] == want, f"task {task}: C host crc {got['crc32']:#x} != oracle {want:#x}"
+    assert got["episodes"] == n and n > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,rollout", [(0, 0), (1, 0), (3, 0), (0, 32)])
+def test_c_host_mp_gather_matches_oracle(exe, oracle, task, rollout):
+    """One rank on the 1-GPU box: fork-before-HIP, RCCL communicator bootstrapped
+    from C, the gathered batch of every launch CRC'd against the oracle."""
+    envs, steps, seed = 8192, 96, 11
+    cmd = [EXE_MP, "--gpus", "1", "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed), "--crc", "1", "--gather", "1"]
+    if rollout:
+        cmd += ["--rollout", str(rollout)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    want, _ = oracle_crc(oracle, task, envs, steps, seed, rollout=rollout)
+    assert got["crc32"] == want, f"task {task}: gathered crc {got['crc32']:#x} != oracle {want:#x}"
+    assert got["env_steps_per_s"] > 0

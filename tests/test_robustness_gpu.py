@@ -1,0 +1,204 @@
+"""Round-2 boundary hardening, on the GPU: the done-id list across fused
+rollouts, checkpoint restore with the step counter, the sticky status of the
+void path calls, the caller's current device, the index-range check, and the
+RCCL gather reached through the C-ABI (one rank on the 1-GPU box)."""
+import numpy as np
+import pytest
+
+from drone_amd import abi
+from helpers import assert_bits_equal, assert_outputs_equal, assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(oracle, hip, n, seed, task=0, device=None, **over):
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, **over), threads=8)
+    h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(task, **over), device=device)
+    o.reset(seed)
+    h.reset(seed)
+    return o, h
+
+
+@pytest.mark.parametrize("odd", [1, 3, 7])
+def test_done_list_survives_odd_rollouts(oracle, hip, odd):
+    """step, rollout(odd), step with compact_done=1: the counter slot is keyed on
+    step launches, not on gstep parity, so the second step starts from zero."""
+    n = 2048
+    o, h = make_pair(oracle, hip, n, 3, 0, horizon=6, compact_done=1)  # horizon 6: every env truncates every 6th step
+    for rnd in range(8):
+        for _ in range(2):
+            o.fill_random_actions()
+            h.actions[:] = o.actions
+            o.step()
+            h.step()
+            want = np.flatnonzero(o.terminals | o.truncations).astype(np.uint32)
+            got = np.sort(h.done_list())
+            assert_bits_equal(want, got, f"round {rnd}: done ids")
+        o.rollout(odd)
+        h.rollout(odd)
+        assert len(h.done_list()) == 0, "a fused rollout builds no list"
+    assert_state_equal(o.get_state(), h.get_state(), "state")
+    assert h.status()[0] == 0
+
+
+def test_all_envs_done_then_rollout_then_step(oracle, hip):
+    """The ADVICE scenario: every env finishes at step g (count = n), an odd rollout,
+    then a step in which some env finishes — must not index past the list."""
+    n = 1024
+    o, h = make_pair(oracle, hip, n, 9, 0, horizon=4, compact_done=1)
+    for _ in range(4):
+        o.fill_random_actions(); h.actions[:] = o.actions; o.step(); h.step()
+    assert len(h.done_list()) == n
+    o.rollout(3); h.rollout(3)
+    o.fill_random_actions(); h.actions[:] = o.actions; o.step(); h.step()  # tick 4 again: all truncate
+    got = np.sort(h.done_list())
+    assert_bits_equal(np.arange(n, dtype=np.uint32), got, "second full list")
+
+
+def test_checkpoint_restore_with_gstep(hip):
+    """Save at step k, restore into a fresh handle (set_state + set_gstep), continue:
+    bit-identical to the uninterrupted run on the waypoint task, whose wind and
+    random policy are keyed on gstep."""
+    n, seed, k, more = 3000, 21, 37, 80
+    a = hip.DroneVec(n, seed=seed, task=abi.TASK_WAYPOINT, horizon=50)
+    a.reset(seed)
+    for _ in range(k):
+        a.fill_random_actions()
+        a.step()
+    rows, g = a.get_state(), a.gstep
+    b = hip.DroneVec(n, seed=seed, task=abi.TASK_WAYPOINT, horizon=50)
+    b.reset(seed)
+    b.set_state(rows)
+    b.set_gstep(g)
+    for _ in range(more):
+        a.fill_random_actions()
+        a.step()
+        b.fill_random_actions()
+        b.step()
+    assert a.gstep == b.gstep == k + more
+    assert_outputs_equal(a, b, "restored run")
+    assert_state_equal(a.get_state(), b.get_state(), "restored state")
+    # without the counter the runs diverge (that is what the entry point is for)
+    c = hip.DroneVec(n, seed=seed, task=abi.TASK_WAYPOINT, horizon=50)
+    c.reset(seed)
+    c.set_state(rows)
+    c.fill_random_actions()
+    c.step()
+    assert not np.array_equal(c.get_state()["wind"], b.get_state()["wind"])
+
+
+def test_sticky_status_and_error_clearing(hip):
+    h = hip.DroneVec(256)
+    h.reset(0)
+    assert h.status() == (0, "")
+    # a failing int-returning call sets the thread's message and sticks to the handle ...
+    with pytest.raises(RuntimeError, match="bad range"):
+        h.get_state(first=200, count=100)
+    assert h.status()[0] != 0 and "bad range" in h.status()[1]
+    # ... so the next void path call raises in the binding instead of passing silently
+    with pytest.raises(RuntimeError, match="bad range"):
+        h.step()
+    h.clear_status()
+    h.step()  # a successful call clears the thread-local text
+    assert hip.last_error() == ""
+    with pytest.raises(RuntimeError, match="horizon must be positive"):
+        h.rollout(0)
+    h.clear_status()
+    g = h.gstep
+    h.rollout(5)
+    assert h.gstep == g + 5
+
+
+def test_callers_device_is_left_alone(hip):
+    """Entry points switch to the handle's device and put the caller's back."""
+    import ctypes as C
+
+    import torch
+
+    hiprt = C.CDLL("libamdhip64.so")
+    cur = C.c_int(-1)
+    h = hip.DroneVec(512, device="cuda:0")
+    h.reset(0)
+    h.step()
+    assert hiprt.hipGetDevice(C.byref(cur)) == 0 and cur.value == torch.cuda.current_device()
+    h.close()
+
+
+def test_num_envs_beyond_32bit_plane_indexing_is_refused(hip):
+    buf = np.zeros(16, dtype=np.float32)
+    f = hip._fns
+    cfg = hip.default_config(0)
+    p = buf.ctypes.data
+    big = (1 << 32) // 9 + 4096  # 9 planes x stride no longer fits 32-bit element indices
+    assert not f["drone_vec_init"](p, p, p, p, p, big, 0, C_byref(cfg))
+    assert "too large" in hip.last_error()
+
+
+def C_byref(x):
+    import ctypes as C
+
+    return C.byref(x)
+
+
+@pytest.mark.parametrize("task,inplace", [(0, True), (1, False), (3, True)])
+def test_c_abi_gather_device_buffers(oracle, hip, task, inplace):
+    """drone_vec_gather on device buffers, one rank: ncclAllGather called from the
+    library on the handle's stream; in-place when the local buffers are the rank's
+    slice of the global ones."""
+    import torch
+
+    n, seed = 20000, 13
+    od = abi.obs_dim(task)
+    dev = torch.device("cuda:0")
+    g_obs = torch.zeros((n, od), dtype=torch.float32, device=dev)
+    g_rew = torch.zeros(n, dtype=torch.float32, device=dev)
+    g_term = torch.zeros(n, dtype=torch.uint8, device=dev)
+    g_trunc = torch.zeros(n, dtype=torch.uint8, device=dev)
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, horizon=30), threads=8)
+    if inplace:
+        bufs = (g_obs, torch.zeros((n, 4), dtype=torch.float32, device=dev), g_rew, g_term, g_trunc)
+        h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(task, horizon=30), buffers=bufs)
+    else:
+        h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(task, horizon=30), device=dev)
+    o.reset(seed)
+    h.reset(seed)
+    h.gather_init(hip.gather_unique_id(), 0, 1, g_obs, g_rew, g_term, g_trunc)
+    for t in range(40):
+        o.fill_random_actions()
+        h.fill_random_actions()
+        o.step()
+        h.step()
+        h.gather()
+        if t % 13 == 0 or t == 39:
+            torch.cuda.synchronize()
+            assert_bits_equal(o.observations, g_obs, f"gathered obs {t}")
+            assert_bits_equal(o.rewards, g_rew, f"gathered rew {t}")
+            assert_bits_equal(o.terminals, g_term, f"gathered term {t}")
+            assert_bits_equal(o.truncations, g_trunc, f"gathered trunc {t}")
+    h.gather_close()
+    h.close()
+
+
+def test_c_abi_gather_host_buffers_ragged_counts(oracle, hip, monkeypatch):
+    """Host-buffer handle + explicit counts, forced onto the all-gather-v branch
+    (one broadcast per rank): the batch lands in the caller's host buffers after each gather."""
+    monkeypatch.setenv("DRONE_GATHER_FORCE_V", "1")
+    n, seed, task = 5000, 4, 1
+    o, h = make_pair(oracle, hip, n, seed, task, horizon=25)
+    g_obs = np.zeros((n, abi.obs_dim(task)), dtype=np.float32)
+    g_rew = np.zeros(n, dtype=np.float32)
+    g_term = np.zeros(n, dtype=np.uint8)
+    g_trunc = np.zeros(n, dtype=np.uint8)
+    h.gather_init(hip.gather_unique_id(), 0, 1, g_obs, g_rew, g_term, g_trunc, counts=[n])
+    for t in range(30):
+        o.fill_random_actions()
+        h.actions[:] = o.actions
+        o.step()
+        h.step()
+        h.gather()
+        assert_bits_equal(o.observations, g_obs, f"obs {t}")
+        assert_bits_equal(o.rewards, g_rew, f"rew {t}")
+        assert_bits_equal(o.terminals, g_term, f"term {t}")
+        assert_bits_equal(o.truncations, g_trunc, f"trunc {t}")
+    assert_outputs_equal(o, h, "local buffers still filled")
+    h.gather_close()

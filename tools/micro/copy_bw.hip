@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 copy_bw.hip -o /tmp/copy_bw
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -67,15 +68,42 @@ void run(const char* name, size_t n) {
     hipFree(out);
 }
 
-int main() {
-    const size_t n = 1 << 20;  // one float4 per env per stream, as in the env kernels
-    run<1, 1, false>("copy 1:1", n * 8);
-    run<7, 10, false>("env-like 7:10 (112 B : 160 B)", n);
-    run<7, 10, true>("env-like 7:10, nt stores", n);
-    run<7, 10, false, true>("env-like 7:10, wave-tiled layout", n);
-    run<7, 10, true, true>("env-like 7:10, wave-tiled, nt", n);
-    run<9, 9, false>("9:9", n);
-    run<0, 15, false>("write only (reset-like)", n);
-    run<15, 1, false>("read mostly 15:1", n);
+// an empty launch of the same grid: the launch-to-launch floor of a dependent stream of kernels
+__global__ __launch_bounds__(256) void empty_kernel(const f4* in, f4* out, size_t n) {}
+
+void run_empty(size_t n) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int reps = 2000;
+    for (int k = 0; k < 20; k++) empty_kernel<<<(n + 255) / 256, 256>>>(nullptr, nullptr, n);
+    hipEventRecord(e0);
+    for (int k = 0; k < reps; k++) empty_kernel<<<(n + 255) / 256, 256>>>(nullptr, nullptr, n);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-34s grid %zu: %7.2f us launch-to-launch\n", "empty kernel", (n + 255) / 256, ms * 1e3 / reps);
+}
+
+// usage: copy_bw [n ...]   (elements per stream = envs; default 2^20)
+int main(int argc, char** argv) {
+    size_t sizes[16];
+    int ns = 0;
+    for (int k = 1; k < argc && ns < 16; k++) sizes[ns++] = (size_t)strtoull(argv[k], nullptr, 10);
+    if (ns == 0) sizes[ns++] = 1 << 20;
+    for (int k = 0; k < ns; k++) {
+        const size_t n = sizes[k];  // one float4 per env per stream, as in the env kernels
+        printf("---- n = %zu elements per stream ----\n", n);
+        run_empty(n);
+        run<1, 1, false>("copy 1:1", n * 8);
+        run<7, 10, false>("env-like 7:10 (112 B : 160 B)", n);
+        run<7, 10, true>("env-like 7:10, nt stores", n);
+        run<7, 10, false, true>("env-like 7:10, wave-tiled layout", n);
+        run<7, 10, true, true>("env-like 7:10, wave-tiled, nt", n);
+        run<9, 9, false>("9:9", n);
+        run<0, 15, false>("write only (reset-like)", n);
+        run<15, 1, false>("read mostly 15:1", n);
+    }
     return 0;
 }
