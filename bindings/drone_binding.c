@@ -1,0 +1,357 @@
+/*
+ * drone_binding.c — the CPython extension a PufferLib-side `binding.c` for this env
+ * would be: vec_init / vec_reset / vec_step / vec_log / vec_close over the caller's
+ * shared buffers, forwarding to the C-ABI of include/drone_vec.h (one HIP launch per
+ * vec call) instead of looping a per-env c_step on the CPU.
+ *
+ * Reference interface replaced: PufferLib ocean envs include a generic
+ * `env_binding.h` that defines these module functions around `c_step` [UNVERIFIED
+ * RECOLLECTION — the reference snapshot has no binding source to cite:
+ * /root/reference/.gitmodules:1-3 names an empty `pufferlib` submodule]. Names,
+ * argument order (five buffers, num_envs, seed, env kwargs) and the dict returned
+ * by vec_log follow that convention as far as the north-star describes it.
+ *
+ * Pure CPython C-API + the buffer protocol: no numpy headers, no HIP headers.
+ *   gcc -O2 -shared -fPIC $(python3-config --includes) -Iinclude bindings/drone_binding.c \
+ *       -Ldrone_amd -l:libdrone_hip.so -Wl,-rpath,'$ORIGIN' -o drone_amd/drone_binding$(python3-config --extension-suffix)
+ *
+ * Buffers: any object exporting a writable C-contiguous buffer (numpy arrays, slices
+ * of a shared-memory block) -> DRONE_BUFFERS_HOST; or objects with `data_ptr()` (torch
+ * tensors on the GPU) -> DRONE_BUFFERS_DEVICE, zero-copy.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stddef.h>
+#include <string.h>
+
+#include "drone_vec.h"
+
+#define CAPSULE_NAME "drone_amd.DroneVec"
+
+typedef struct Handle {
+    DroneVec* v;
+    Py_buffer views[5]; /* host mode: keeps the exporters' memory pinned while the env uses it */
+    int n_views;
+    PyObject* keep[5];  /* device mode: strong references to the tensors */
+    int n_keep;
+} Handle;
+
+static void handle_free(Handle* h) {
+    if (!h) return;
+    if (h->v) drone_vec_close(h->v);
+    for (int i = 0; i < h->n_views; i++) PyBuffer_Release(&h->views[i]);
+    for (int i = 0; i < h->n_keep; i++) Py_XDECREF(h->keep[i]);
+    PyMem_Free(h);
+}
+
+static void capsule_destructor(PyObject* cap) {
+    Handle* h = (Handle*)PyCapsule_GetPointer(cap, CAPSULE_NAME);
+    if (!h) { PyErr_Clear(); return; }
+    handle_free(h);
+}
+
+static Handle* get_handle(PyObject* cap) {
+    Handle* h = (Handle*)PyCapsule_GetPointer(cap, CAPSULE_NAME);
+    if (!h) return NULL;
+    if (!h->v) { PyErr_SetString(PyExc_ValueError, "env handle is closed"); return NULL; }
+    return h;
+}
+
+static int raise_if_failed(Handle* h) {
+    if (drone_vec_status(h->v)) {
+        PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_vec_status_message(h->v));
+        return -1;
+    }
+    return 0;
+}
+
+/* ---- kwargs -> DroneConfig ---- */
+typedef struct Field { const char* name; char kind; size_t off; } Field; /* kind: 'i' int32, 'u' uint32, 'f' float */
+#define F_(name, kind) {#name, kind, offsetof(DroneConfig, name)}
+static const Field kFields[] = {
+    F_(task, 'i'), F_(device, 'i'), F_(env_offset, 'u'), F_(horizon, 'i'), F_(substeps, 'i'), F_(compact_done, 'i'), F_(agents_per_env, 'i'),
+    F_(dt, 'f'), F_(mass, 'f'), F_(arm, 'f'), F_(ixx, 'f'), F_(iyy, 'f'), F_(izz, 'f'),
+    F_(k_thrust, 'f'), F_(k_torque, 'f'), F_(k_drag, 'f'), F_(k_ang_damp, 'f'), F_(gravity, 'f'),
+    F_(max_rpm, 'f'), F_(motor_tau, 'f'), F_(max_vel, 'f'), F_(max_omega, 'f'),
+    F_(bound, 'f'), F_(spawn_extent, 'f'), F_(target_extent, 'f'), F_(tilt_init, 'f'),
+    F_(hover_radius, 'f'), F_(waypoint_radius, 'f'), F_(wind_theta, 'f'), F_(wind_sigma, 'f'), F_(wind_max, 'f'),
+    F_(c_omega, 'f'), F_(c_action, 'f'), F_(crash_penalty, 'f'), F_(progress_scale, 'f'), F_(waypoint_bonus, 'f'),
+    F_(collision_radius, 'f'), F_(proximity_radius, 'f'), F_(c_proximity, 'f'), F_(gate_radius, 'f'),
+};
+#undef F_
+
+static int apply_kwargs(DroneConfig* cfg, PyObject* kwargs) {
+    if (!kwargs) return 0;
+    PyObject *key, *val;
+    Py_ssize_t pos = 0;
+    while (PyDict_Next(kwargs, &pos, &key, &val)) {
+        const char* k = PyUnicode_AsUTF8(key);
+        if (!k) return -1;
+        if (!strcmp(k, "task")) continue; /* consumed before drone_config_default */
+        const Field* f = NULL;
+        for (size_t i = 0; i < sizeof(kFields) / sizeof(kFields[0]); i++)
+            if (!strcmp(k, kFields[i].name)) { f = &kFields[i]; break; }
+        if (!f) { PyErr_Format(PyExc_TypeError, "vec_init: unknown env kwarg '%s'", k); return -1; }
+        char* dst = (char*)cfg + f->off;
+        if (f->kind == 'f') {
+            const double d = PyFloat_AsDouble(val);
+            if (d == -1.0 && PyErr_Occurred()) return -1;
+            *(float*)dst = (float)d;
+        } else {
+            const long long x = PyLong_AsLongLong(val);
+            if (x == -1 && PyErr_Occurred()) return -1;
+            if (f->kind == 'u') *(uint32_t*)dst = (uint32_t)x;
+            else *(int32_t*)dst = (int32_t)x;
+        }
+    }
+    return 0;
+}
+
+/* a device tensor: has data_ptr(); returns 1 and the address, 0 if not that kind, -1 on error */
+static int device_pointer(PyObject* o, void** out) {
+    if (!PyObject_HasAttrString(o, "data_ptr")) return 0;
+    PyObject* r = PyObject_CallMethod(o, "data_ptr", NULL);
+    if (!r) return -1;
+    *out = PyLong_AsVoidPtr(r);
+    Py_DECREF(r);
+    if (PyErr_Occurred()) return -1;
+    return 1;
+}
+
+/* vec_init(observations, actions, rewards, terminals, truncations, num_envs, seed, **env_kwargs) -> handle */
+static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
+    (void)self;
+    PyObject* bufs[5];
+    int num_envs;
+    unsigned long long seed;
+    if (!PyArg_ParseTuple(args, "OOOOOiK", &bufs[0], &bufs[1], &bufs[2], &bufs[3], &bufs[4], &num_envs, &seed)) return NULL;
+    if (num_envs <= 0) { PyErr_SetString(PyExc_ValueError, "num_envs must be positive"); return NULL; }
+
+    int task = DRONE_TASK_HOVER;
+    if (kwargs) {
+        PyObject* t = PyDict_GetItemString(kwargs, "task");
+        if (t) {
+            task = (int)PyLong_AsLong(t);
+            if (task == -1 && PyErr_Occurred()) return NULL;
+        }
+    }
+    DroneConfig cfg;
+    drone_config_default(&cfg, task);
+    if (apply_kwargs(&cfg, kwargs) < 0) return NULL;
+
+    Handle* h = (Handle*)PyMem_Calloc(1, sizeof(Handle));
+    if (!h) return PyErr_NoMemory();
+    void* ptr[5] = {0};
+    const size_t od = (size_t)drone_obs_dim(task);
+    const size_t need[5] = {(size_t)num_envs * od * 4, (size_t)num_envs * DRONE_ACT_DIM * 4, (size_t)num_envs * 4, (size_t)num_envs, (size_t)num_envs};
+    static const char* names[5] = {"observations", "actions", "rewards", "terminals", "truncations"};
+    int kind = -1; /* 0 host, 1 device */
+    for (int i = 0; i < 5; i++) {
+        void* d = NULL;
+        const int isdev = device_pointer(bufs[i], &d);
+        if (isdev < 0) { handle_free(h); return NULL; }
+        if (kind >= 0 && kind != isdev) {
+            PyErr_SetString(PyExc_TypeError, "vec_init: buffers must be all host buffers or all device tensors");
+            handle_free(h);
+            return NULL;
+        }
+        kind = isdev;
+        if (isdev) {
+            /* size check through numel() * element_size() when the object offers them (torch tensors do) */
+            PyObject* ne = PyObject_CallMethod(bufs[i], "numel", NULL);
+            PyObject* es = ne ? PyObject_CallMethod(bufs[i], "element_size", NULL) : NULL;
+            if (!ne || !es) { Py_XDECREF(ne); Py_XDECREF(es); handle_free(h); return NULL; }
+            const size_t have = (size_t)PyLong_AsSize_t(ne) * (size_t)PyLong_AsSize_t(es);
+            Py_DECREF(ne);
+            Py_DECREF(es);
+            if (have < need[i]) { PyErr_Format(PyExc_ValueError, "vec_init: %s holds %zu bytes, %zu needed", names[i], have, need[i]); handle_free(h); return NULL; }
+            Py_INCREF(bufs[i]);
+            h->keep[h->n_keep++] = bufs[i];
+            ptr[i] = d;
+        } else {
+            if (PyObject_GetBuffer(bufs[i], &h->views[h->n_views], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) { handle_free(h); return NULL; }
+            h->n_views++;
+            if ((size_t)h->views[i].len < need[i]) {
+                PyErr_Format(PyExc_ValueError, "vec_init: %s holds %zd bytes, %zu needed", names[i], h->views[i].len, need[i]);
+                handle_free(h);
+                return NULL;
+            }
+            ptr[i] = h->views[i].buf;
+        }
+    }
+    cfg.buffer_kind = kind ? DRONE_BUFFERS_DEVICE : DRONE_BUFFERS_HOST;
+    Py_BEGIN_ALLOW_THREADS
+    h->v = drone_vec_init((float*)ptr[0], (float*)ptr[1], (float*)ptr[2], (unsigned char*)ptr[3], (unsigned char*)ptr[4], num_envs, seed, &cfg);
+    Py_END_ALLOW_THREADS
+    if (!h->v) {
+        PyErr_Format(PyExc_RuntimeError, "drone_vec_init failed: %s", drone_last_error());
+        handle_free(h);
+        return NULL;
+    }
+    PyObject* cap = PyCapsule_New(h, CAPSULE_NAME, capsule_destructor);
+    if (!cap) handle_free(h);
+    return cap;
+}
+
+static PyObject* vec_reset(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    unsigned long long seed = 0;
+    if (!PyArg_ParseTuple(args, "O|K", &cap, &seed)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    Py_BEGIN_ALLOW_THREADS
+    drone_vec_reset(h->v, seed);
+    Py_END_ALLOW_THREADS
+    if (raise_if_failed(h) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+static PyObject* vec_step(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    Py_BEGIN_ALLOW_THREADS
+    drone_vec_step(h->v);
+    Py_END_ALLOW_THREADS
+    if (raise_if_failed(h) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+/* vec_rollout(handle, horizon): fused rollout under the device-side random policy (SPEC.md §9) */
+static PyObject* vec_rollout(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    int horizon;
+    if (!PyArg_ParseTuple(args, "Oi", &cap, &horizon)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    Py_BEGIN_ALLOW_THREADS
+    drone_vec_rollout(h->v, horizon);
+    Py_END_ALLOW_THREADS
+    if (raise_if_failed(h) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+static PyObject* vec_log(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    DroneLog l;
+    Py_BEGIN_ALLOW_THREADS
+    drone_vec_log(h->v, &l);
+    Py_END_ALLOW_THREADS
+    if (raise_if_failed(h) < 0) return NULL;
+    return Py_BuildValue("{s:f,s:f,s:f,s:f,s:f,s:f}", "perf", l.perf, "score", l.score, "episode_return", l.episode_return,
+                         "episode_length", l.episode_length, "oob", l.oob, "n", l.n);
+}
+
+static PyObject* vec_close(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = (Handle*)PyCapsule_GetPointer(cap, CAPSULE_NAME);
+    if (!h) return NULL;
+    if (h->v) {
+        drone_vec_close(h->v);
+        h->v = NULL;
+    }
+    for (int i = 0; i < h->n_views; i++) PyBuffer_Release(&h->views[i]);
+    h->n_views = 0;
+    for (int i = 0; i < h->n_keep; i++) Py_XDECREF(h->keep[i]);
+    h->n_keep = 0;
+    Py_RETURN_NONE;
+}
+
+/* vec_set_stream(handle, hip_stream_address): device-buffer mode launches on this stream from now on */
+static PyObject* vec_set_stream(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    unsigned long long s;
+    if (!PyArg_ParseTuple(args, "OK", &cap, &s)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    if (drone_vec_set_stream(h->v, (void*)(uintptr_t)s) != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
+    Py_RETURN_NONE;
+}
+
+/* vec_fill_random_actions(handle, actions=None, gstep=None): the SPEC.md §2 random policy into the action buffer */
+static PyObject* vec_fill_random_actions(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject *cap, *buf = Py_None, *gs = Py_None;
+    if (!PyArg_ParseTuple(args, "O|OO", &cap, &buf, &gs)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    uint32_t g = drone_vec_gstep(h->v);
+    if (gs != Py_None) {
+        g = (uint32_t)PyLong_AsUnsignedLongMask(gs);
+        if (PyErr_Occurred()) return NULL;
+    }
+    void* p = NULL;
+    Py_buffer view;
+    int have_view = 0;
+    if (buf == Py_None) {
+        p = h->n_views ? h->views[1].buf : NULL;
+        if (!p && h->n_keep && device_pointer(h->keep[1], &p) < 0) return NULL;
+    } else {
+        const int isdev = device_pointer(buf, &p);
+        if (isdev < 0) return NULL;
+        if (!isdev) {
+            if (PyObject_GetBuffer(buf, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) return NULL;
+            have_view = 1;
+            p = view.buf;
+        }
+    }
+    const int rc = drone_vec_fill_random_actions(h->v, (float*)p, g);
+    if (have_view) PyBuffer_Release(&view);
+    if (rc != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
+    Py_RETURN_NONE;
+}
+
+static PyObject* vec_gstep(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    return PyLong_FromUnsignedLong(drone_vec_gstep(h->v));
+}
+
+static PyObject* obs_dim(PyObject* self, PyObject* args) {
+    (void)self;
+    int task;
+    if (!PyArg_ParseTuple(args, "i", &task)) return NULL;
+    return PyLong_FromLong(drone_obs_dim(task));
+}
+
+static PyMethodDef methods[] = {
+    {"vec_init", (PyCFunction)(void (*)(void))vec_init, METH_VARARGS | METH_KEYWORDS,
+     "vec_init(observations, actions, rewards, terminals, truncations, num_envs, seed, **env_kwargs) -> handle"},
+    {"vec_reset", vec_reset, METH_VARARGS, "vec_reset(handle, seed=0)"},
+    {"vec_step", vec_step, METH_VARARGS, "vec_step(handle): read actions, advance every env, overwrite the output buffers"},
+    {"vec_rollout", vec_rollout, METH_VARARGS, "vec_rollout(handle, horizon): fused rollout under the device-side random policy"},
+    {"vec_log", vec_log, METH_VARARGS, "vec_log(handle) -> dict(perf, score, episode_return, episode_length, oob, n)"},
+    {"vec_close", vec_close, METH_VARARGS, "vec_close(handle)"},
+    {"vec_set_stream", vec_set_stream, METH_VARARGS, "vec_set_stream(handle, hip_stream_address)"},
+    {"vec_fill_random_actions", vec_fill_random_actions, METH_VARARGS, "vec_fill_random_actions(handle, actions=None, gstep=None)"},
+    {"vec_gstep", vec_gstep, METH_VARARGS, "vec_gstep(handle) -> int"},
+    {"obs_dim", obs_dim, METH_VARARGS, "obs_dim(task) -> floats per observation row"},
+    {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "drone_binding", "PufferLib-style vec binding of the MI355X drone env (C-ABI: include/drone_vec.h)", -1,
+                                       methods, NULL, NULL, NULL, NULL};
+
+PyMODINIT_FUNC PyInit_drone_binding(void) {
+    PyObject* m = PyModule_Create(&moduledef);
+    if (!m) return NULL;
+    PyModule_AddIntConstant(m, "TASK_HOVER", DRONE_TASK_HOVER);
+    PyModule_AddIntConstant(m, "TASK_WAYPOINT", DRONE_TASK_WAYPOINT);
+    PyModule_AddIntConstant(m, "TASK_SWARM", DRONE_TASK_SWARM);
+    PyModule_AddIntConstant(m, "TASK_RACE", DRONE_TASK_RACE);
+    PyModule_AddIntConstant(m, "ACT_DIM", DRONE_ACT_DIM);
+    return m;
+}

@@ -77,3 +77,183 @@ def obs(c, S, target):
     body = lambda u: np.einsum("nij,ni->nj", R, u)  # R^T u
     return np.concatenate([body(v) / c["max_vel"], o / c["max_omega"], q, r / c["max_rpm"],
                            body(target - p) * (0.5 / c["bound"]), p / c["bound"]], 1)
+
+
+# =====================================================================
+# Round 2: the WHOLE env step (SPEC.md §2, §5, §6, §7, §11) restated independently:
+# integer counter RNG in numpy uint64 (masked to 32 bits), wind, reward, episode
+# end, reset draws, waypoint / gate dealing, log sums — float64 throughout.
+# Used one step ahead (tests/test_oracle_independent.py): every step starts from
+# the oracle's float32 state, so rounding error never accumulates and every
+# branch — resets included — is compared at ~1e-6.
+# =====================================================================
+_M = np.uint64(0xFFFFFFFF)
+
+
+def _u(x):
+    return np.asarray(x, dtype=np.uint64) & _M
+
+
+def hash32(x):
+    x = _u(x)
+    x = x ^ (x >> np.uint64(16))
+    x = (x * np.uint64(0x7FEB352D)) & _M
+    x = x ^ (x >> np.uint64(15))
+    x = (x * np.uint64(0x846CA68B)) & _M
+    x = x ^ (x >> np.uint64(16))
+    return x
+
+
+def stream_key(seed, stream):
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    return int(hash32(lo ^ int(hash32(hi ^ ((0x9E3779B9 * (stream + 1)) & 0xFFFFFFFF)))))
+
+
+def rng_base(key, env, ctr):
+    return hash32((hash32(_u(key) ^ _u(env)) + _u(ctr) * np.uint64(0x9E3779B9)) & _M)
+
+
+def rng_draw(base, d):
+    return hash32((_u(base) + _u(d) * np.uint64(0x85EBCA6B)) & _M)
+
+
+def sym(u):
+    return 2.0 * ((_u(u) >> np.uint64(8)).astype(np.float64) * 2.0 ** -24) - 1.0
+
+
+RESET, ACTION, WIND, WAYPOINT = 0, 1, 2, 3
+
+
+def random_actions(seed, env, gstep):
+    b = rng_base(stream_key(seed, ACTION), env, gstep)
+    h0, h1 = rng_draw(b, 0), rng_draw(b, 1)
+    s16 = lambda h: (h.astype(np.int64) - 32768) / 32768.0
+    return np.stack([s16(h0 & np.uint64(0xFFFF)), s16(h0 >> np.uint64(16)), s16(h1 & np.uint64(0xFFFF)), s16(h1 >> np.uint64(16))], 1)
+
+
+def unit(e):
+    return e / np.sqrt((e * e).sum(1, keepdims=True) + 1e-12)
+
+
+def reset_draws(c, seed, env, episode, task):
+    """SPEC.md §6 (+ §11 for the first gate normal): the fresh state of episode `episode` of global env `env`."""
+    b = rng_base(stream_key(seed, RESET), env, episode)
+    u = [sym(rng_draw(b, k)) for k in range(9)]
+    pos = c["spawn_extent"] * np.stack(u[0:3], 1)
+    tgt = c["target_extent"] * np.stack(u[3:6], 1)
+    t = c["tilt_init"] * np.stack(u[6:9], 1)
+    quat = np.concatenate([np.ones((len(pos), 1)), t], 1)
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    n = len(pos)
+    out = {"pos": pos, "vel": np.zeros((n, 3)), "quat": quat, "omega": np.zeros((n, 3)), "rpm": np.full((n, 4), c["hover_rpm"]),
+           "target": tgt, "wind": np.zeros((n, 3))}
+    if task == 3:
+        out["wind"] = unit(tgt - pos)
+    return out
+
+
+def full_obs(c, S, target, aux, task):
+    o = obs(c, S, target)
+    if task == 3:
+        p, v, q, om, r = S
+        R = rot(q)
+        nb = np.einsum("nij,ni->nj", R, aux)
+        d = ((p - target) * aux).sum(1, keepdims=True) / c["bound"]
+        o = np.concatenate([o, nb, d], 1)
+    return o
+
+
+def env_step(c, seed, task, st, actions, gstep, env_ids):
+    """One SPEC.md §5 step for tasks 0, 1, 3 from the state rows `st` (a dict of float64 / int arrays).
+    Returns the new rows, (reward, terminal, truncation), the observation, and `margin`: how far the
+    closest discontinuity (box wall, hover / waypoint radius, gate plane, ring rim) was from deciding
+    differently — the caller ignores envs whose margin is at rounding level."""
+    n = len(env_ids)
+    a = np.clip(actions, -1, 1)
+    wind = st["wind"].copy()
+    pos0 = st["pos"].copy()
+    tgt = st["target"].copy()
+    margin = np.full(n, np.inf)
+    if task == 1:
+        b = rng_base(stream_key(seed, WIND), env_ids, gstep)
+        decay = 1.0 - c["wind_theta"] * c["dt"]
+        gain = c["wind_sigma"] * np.sqrt(c["dt"]) / np.sqrt(21845.0)
+        for k in range(3):
+            u = rng_draw(b, k)
+            s = (u & np.uint64(255)) + ((u >> np.uint64(8)) & np.uint64(255)) + ((u >> np.uint64(16)) & np.uint64(255)) + (u >> np.uint64(24))
+            wind[:, k] = np.clip(decay * wind[:, k] + gain * (s.astype(np.float64) - 510.0), -c["wind_max"], c["wind_max"])
+    prev_dist = np.linalg.norm(tgt - pos0, axis=1)
+    S = [st["pos"], st["vel"], st["quat"], st["omega"], st["rpm"]]
+    S = step(c, S, a, wind if task == 1 else np.zeros((n, 3)))
+    p, v, q, o, r = S
+    tick = st["tick"] + 1
+    dist = np.linalg.norm(tgt - p, axis=1)
+    oob = (np.abs(p) > c["bound"]).any(1) | ~np.isfinite(p).all(1)
+    margin = np.minimum(margin, np.abs(np.abs(p) - c["bound"]).min(1))
+    trunc = ~oob & (tick >= c["horizon"])
+    pen = c["c_omega"] * (o * o).sum(1) + c["c_action"] * (a * a).sum(1)
+    score = st["score_count"].copy()
+    aux = wind.copy() if task == 1 else st["wind"].copy()
+    episode = st["episode"].copy()
+    if task == 0:
+        rew = 1.0 - dist * (0.5 / c["bound"]) - pen
+        score = score + (dist < c["hover_radius"])
+        margin = np.minimum(margin, np.abs(dist - c["hover_radius"]))
+    elif task == 1:
+        rew = c["progress_scale"] * (prev_dist - dist) - pen
+        hit = ~oob & (dist < c["waypoint_radius"])
+        margin = np.minimum(margin, np.abs(dist - c["waypoint_radius"]))
+        rew = rew + hit * c["waypoint_bonus"]
+        score = score + hit
+        b = rng_base(stream_key(seed, WAYPOINT), env_ids, episode)
+        new_t = c["target_extent"] * np.stack([sym(rng_draw(b, 3 * score + k)) for k in range(3)], 1)
+        tgt = np.where(hit[:, None], new_t, tgt)
+    else:
+        rew = c["progress_scale"] * (prev_dist - dist) - pen
+        nrm = st["wind"]
+        s0 = (nrm * (pos0 - tgt)).sum(1)
+        s1 = (nrm * (p - tgt)).sum(1)
+        cross = ~oob & (s0 < 0) & (s1 >= 0)
+        margin = np.minimum(margin, np.minimum(np.abs(s0), np.abs(s1)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(cross, s0 / (s0 - s1), 0.0)
+        x = pos0 + t[:, None] * (p - pos0)
+        m2 = ((x - tgt) ** 2).sum(1)
+        gate_r2 = c["gate_radius"] ** 2
+        margin = np.where(cross, np.minimum(margin, np.abs(m2 - gate_r2)), margin)
+        passed = cross & (m2 < gate_r2)
+        rew = rew + passed * c["waypoint_bonus"]
+        score = score + passed
+        b = rng_base(stream_key(seed, WAYPOINT), env_ids, episode)
+        new_c = c["target_extent"] * np.stack([sym(rng_draw(b, 3 * score + k)) for k in range(3)], 1)
+        new_n = unit(new_c - tgt)
+        aux = np.where(passed[:, None], new_n, aux)
+        tgt = np.where(passed[:, None], new_c, tgt)
+    rew = rew - oob * c["crash_penalty"]
+    ep_return = st["ep_return"] + rew
+    done = oob | trunc
+    logs = {k: st[k].copy() for k in ("perf_sum", "score_sum", "ret_sum", "len_sum", "n_sum", "oob_sum")}
+    if task == 0:
+        sc = score / np.maximum(tick, 1)
+        perf = sc
+    else:
+        sc = score.astype(np.float64)
+        perf = np.where(score >= 8, 1.0, score * 0.125)
+    logs["perf_sum"] += done * perf
+    logs["score_sum"] += done * sc
+    logs["ret_sum"] += done * ep_return
+    logs["len_sum"] += done * tick
+    logs["n_sum"] += done * 1.0
+    logs["oob_sum"] += (done & oob) * 1.0
+    episode = episode + done
+    fresh = reset_draws(c, seed, env_ids, episode, task)
+    new = {"pos": p, "vel": v, "quat": q, "omega": o, "rpm": r, "target": tgt, "wind": aux}
+    for k in new:
+        new[k] = np.where(done[:, None], fresh[k], new[k])
+    new["tick"] = np.where(done, 0, tick)
+    new["score_count"] = np.where(done, 0, score)
+    new["ep_return"] = np.where(done, 0.0, ep_return)
+    new["episode"] = episode
+    new.update(logs)
+    S2 = [new[k] for k in ("pos", "vel", "quat", "omega", "rpm")]
+    return new, (rew, oob, trunc), full_obs(c, S2, new["target"], new["wind"], task), margin
