@@ -11,10 +11,12 @@ namespace drone {
 
 // Device pointers for one shard of envs.
 struct DeviceView {
-    float4* planes;      // [kNumPlanes][stride]
+    float4* planes;      // hot state: [n_pad / 64][hot_planes(task)][64]  (drone_params.hpp)
+    float4* cold;        // the two log planes: [2][stride]
     uint32_t n;          // envs on this device
     uint32_t n_pad;      // n rounded up to a whole workgroup: lanes [n, n_pad) exist and hold a valid reset state
-    uint32_t stride;     // float4 elements between consecutive planes (>= n_pad; padded so planes start on different HBM channels)
+    uint32_t stride;     // float4 elements between the two cold planes (>= n_pad)
+    uint32_t line_complete; // 1: rare per-lane plane updates go out as whole 128-B lines (working set beyond the Infinity Cache)
     const uint32_t* kp;  // KParams in HBM (kParamWords words) — read only by the LDS-staging build
     const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)
     float* obs;          // [n][20] (24 for the swarm task)
@@ -22,6 +24,7 @@ struct DeviceView {
     float* rew;          // [n]
     unsigned char* term; // [n]
     unsigned char* trunc;// [n]
+    float* pad_sink;     // [kBlock] floats: where the padding lanes [n, n_pad) of the last workgroup drop their reward
     uint32_t* done_ids;  // [n] or null
     uint32_t* done_count;// [2] ping-pong per step launch, or null
 };

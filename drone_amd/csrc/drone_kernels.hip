@@ -39,11 +39,28 @@
 #ifndef DRONE_XCD_REMAP  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the envs (-3 % step)
 #define DRONE_XCD_REMAP 1
 #endif
-#ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset
-#define DRONE_STEP_MIN_WAVES 0
+#ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset. 5 keeps the race task at 93 VGPRs (97 unbounded), no scratch
+#define DRONE_STEP_MIN_WAVES 5
 #endif
 #ifndef DRONE_STEP_MAX_WAVES  // >0: cap waves per SIMD of the per-step kernel (amdgpu_waves_per_eu)
 #define DRONE_STEP_MAX_WAVES 0
+#endif
+
+#ifndef DRONE_STEP_TILES  // 256-drone chunks per workgroup of the per-step kernel, software-pipelined: the loads of chunk k+1 are in flight while chunk k computes
+#define DRONE_STEP_TILES 1
+#endif
+
+#ifndef DRONE_LOG_FOLD_LATE  // 1: the log-plane read-modify-write of an ended episode completes at the very end of the chunk; 0: right after the state stores
+#define DRONE_LOG_FOLD_LATE 1
+#endif
+
+// MEASUREMENT ONLY (results are wrong with either): drop the log-plane read-modify-write / the target-plane rewrite
+// of ended episodes, to price those scattered 16-byte accesses (tools/ab_step.py)
+#ifndef DRONE_EXP_NO_LOG
+#define DRONE_EXP_NO_LOG 0
+#endif
+#ifndef DRONE_EXP_NO_PT
+#define DRONE_EXP_NO_PT 0
 #endif
 
 #ifndef DRONE_ROLLOUT_MIN_WAVES  // __launch_bounds__ 2nd argument of the fused rollout kernel; 0 = unset
@@ -104,15 +121,48 @@ __device__ __forceinline__ void state_store(float4* p, const float4& v) {
 #endif
 }
 
+// A scattered 16-byte store into HBM is a partial-line write: the memory controller turns it into a read-modify-write
+// that holds its channel ~100 ns (measured: one such store per ended episode, 0.8 % of the lanes, cost 5 % of the
+// step kernel at 2^22 envs; profiles/r02_ab/ab_ends_*.txt). So rare per-lane plane updates are widened to whole
+// 128-byte lines: if any of the 8 lanes that share a line needs the update, all 8 store (the others rewrite what they
+// hold). `m` is a ballot mask; the result has every aligned group of 8 bits set in which `m` had a bit. While the
+// step's working set fits the 256 MiB Infinity Cache the partial writes are absorbed there and the widening only adds
+// bytes (+0.6 % at 2^20 envs), so the host enables it per handle by footprint (DeviceView::line_complete).
+__device__ __forceinline__ uint64_t whole_lines(uint64_t m, uint32_t enabled) {
+    if (!enabled) return m;  // wave-uniform (a launch argument)
+    m |= m >> 1;
+    m |= m >> 2;
+    m |= m >> 4;
+    return (m & 0x0101010101010101ull) * 0xFFull;
+}
+__device__ __forceinline__ bool lane_bit(uint64_t m) { return (m >> (threadIdx.x & (kWave - 1))) & 1ull; }
+
 // ---- plane <-> register marshalling ----
+// one lane's state as it sits in HBM: issued as a block of loads, unpacked when first needed, so that a
+// workgroup can have the NEXT chunk's loads in flight while it computes the current one
 template <int TASK>
-__device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_t np, uint32_t i, Lane& L) {
-    const float4 a = pl[kP0 * np + i];
-    const float4 b = pl[kP1 * np + i];
-    const float4 c = pl[kP2 * np + i];
-    const float4 d = pl[kP3 * np + i];
-    const float4 e = pl[kP4 * np + i];
-    const float4 t = pl[kPT * np + i];
+struct RawLane {
+    float4 a, b, c, d, e, t, w, act;
+};
+
+// No branches in here: the wait-count pass merges the outstanding-load state of all paths into a join and would
+// make the consumer of the CURRENT chunk wait for the prefetched one too. `ia` is the action row to read, already
+// clamped into the buffer by the caller (lanes >= n read the last row and never store anything).
+template <int TASK>
+__device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawLane<TASK>& R) {
+    R.a = pl[hot_index(hot_planes(TASK), kP0, i, np)];
+    R.b = pl[hot_index(hot_planes(TASK), kP1, i, np)];
+    R.c = pl[hot_index(hot_planes(TASK), kP2, i, np)];
+    R.d = pl[hot_index(hot_planes(TASK), kP3, i, np)];
+    R.e = pl[hot_index(hot_planes(TASK), kP4, i, np)];
+    R.t = pl[hot_index(hot_planes(TASK), kPT, i, np)];
+    if (has_aux_plane<TASK>()) R.w = pl[hot_index(hot_planes(TASK), kPW, i, np)];
+    R.act = reinterpret_cast<const float4*>(actions)[ia];
+}
+
+template <int TASK>
+__device__ __forceinline__ void unpack_lane(const RawLane<TASK>& R, Lane& L, float (&act)[4]) {
+    const float4 &a = R.a, &b = R.b, &c = R.c, &d = R.d, &e = R.e, &t = R.t;
     L.s.p[0] = a.x; L.s.p[1] = a.y; L.s.p[2] = a.z; L.s.v[0] = a.w;
     L.s.v[1] = b.x; L.s.v[2] = b.y; L.s.q[0] = b.z; L.s.q[1] = b.w;
     L.s.q[2] = c.x; L.s.q[3] = c.y; L.s.o[0] = c.z; L.s.o[1] = c.w;
@@ -120,7 +170,29 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
     L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
     L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
     if (has_aux_plane<TASK>()) {
-        const float4 w = pl[kPW * np + i];
+        L.wind[0] = R.w.x; L.wind[1] = R.w.y; L.wind[2] = R.w.z;
+    } else {
+        L.wind[0] = L.wind[1] = L.wind[2] = 0.0f;
+    }
+    act[0] = R.act.x; act[1] = R.act.y; act[2] = R.act.z; act[3] = R.act.w;
+}
+
+template <int TASK>
+__device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_t np, uint32_t i, Lane& L) {
+    const float4 a = pl[hot_index(hot_planes(TASK), kP0, i, np)];
+    const float4 b = pl[hot_index(hot_planes(TASK), kP1, i, np)];
+    const float4 c = pl[hot_index(hot_planes(TASK), kP2, i, np)];
+    const float4 d = pl[hot_index(hot_planes(TASK), kP3, i, np)];
+    const float4 e = pl[hot_index(hot_planes(TASK), kP4, i, np)];
+    const float4 t = pl[hot_index(hot_planes(TASK), kPT, i, np)];
+    L.s.p[0] = a.x; L.s.p[1] = a.y; L.s.p[2] = a.z; L.s.v[0] = a.w;
+    L.s.v[1] = b.x; L.s.v[2] = b.y; L.s.q[0] = b.z; L.s.q[1] = b.w;
+    L.s.q[2] = c.x; L.s.q[3] = c.y; L.s.o[0] = c.z; L.s.o[1] = c.w;
+    L.s.o[2] = d.x; L.s.r[0] = d.y; L.s.r[1] = d.z; L.s.r[2] = d.w;
+    L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
+    L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
+    if (has_aux_plane<TASK>()) {
+        const float4 w = pl[hot_index(hot_planes(TASK), kPW, i, np)];
         L.wind[0] = w.x; L.wind[1] = w.y; L.wind[2] = w.z;
     } else {
         L.wind[0] = L.wind[1] = L.wind[2] = 0.0f;
@@ -129,14 +201,14 @@ __device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_
 
 template <int TASK>
 __device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np, uint32_t i, const Lane& L, bool target_changed) {
-    state_store(&pl[kP0 * np + i], make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]));
-    state_store(&pl[kP1 * np + i], make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]));
-    state_store(&pl[kP2 * np + i], make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]));
-    state_store(&pl[kP3 * np + i], make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]));
-    state_store(&pl[kP4 * np + i], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
-    if (target_changed) pl[kPT * np + i] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
+    state_store(&pl[hot_index(hot_planes(TASK), kP0, i, np)], make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]));
+    state_store(&pl[hot_index(hot_planes(TASK), kP1, i, np)], make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]));
+    state_store(&pl[hot_index(hot_planes(TASK), kP2, i, np)], make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]));
+    state_store(&pl[hot_index(hot_planes(TASK), kP3, i, np)], make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]));
+    state_store(&pl[hot_index(hot_planes(TASK), kP4, i, np)], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
+    if (target_changed && !DRONE_EXP_NO_PT) pl[hot_index(hot_planes(TASK), kPT, i, np)] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
     // wind changes every step; a gate normal only together with its centre
-    if (TASK == DRONE_TASK_WAYPOINT || (TASK == DRONE_TASK_RACE && target_changed)) pl[kPW * np + i] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
+    if (TASK == DRONE_TASK_WAYPOINT || (TASK == DRONE_TASK_RACE && target_changed)) pl[hot_index(hot_planes(TASK), kPW, i, np)] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
 }
 
 // per-env log sums: touched only when an episode ended
@@ -158,7 +230,7 @@ struct StepArgs {
 // LDS of one workgroup
 struct Shared {
     float4 obs_tile[kWavesPerBlock][kWave * kObsVecMax];  // wave-private observation tiles
-    uint64_t masks[2][kWavesPerBlock];                 // ballot masks: [terminal | truncation][wave]
+    uint64_t masks[2][2][kWavesPerBlock];              // ballot masks: [chunk parity][terminal | truncation][wave]
 #if DRONE_PARAMS_IN_LDS
     KParams kp;
 #endif
@@ -183,7 +255,7 @@ __device__ __forceinline__ uint32_t spread4(uint32_t nib) { return ((nib & 0xFu)
 // Every thread of the workgroup must call this (it contains the barrier).
 template <int OBSV>
 __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, uint32_t flags_aligned, const float (&o)[DRONE_OBS_DIM_MAX],
-                                              bool term, bool trunc, uint32_t i, uint32_t block_base) {
+                                              bool term, bool trunc, uint32_t i, uint32_t block_base, uint32_t parity = 0) {
     const uint32_t n = v.n;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
@@ -191,9 +263,11 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
     const bool valid = i < n;
     const uint64_t m_term = __ballot(valid && term);
     const uint64_t m_trunc = __ballot(valid && trunc);
+    // a workgroup that walks several chunks alternates between two mask sets: the one barrier per chunk keeps its
+    // waves at most one chunk apart
     if (lane == 0) {
-        sh.masks[0][wave] = m_term;
-        sh.masks[1][wave] = m_trunc;
+        sh.masks[parity][0][wave] = m_term;
+        sh.masks[parity][1][wave] = m_trunc;
     }
     float4* tile = sh.obs_tile[wave];
 #pragma unroll
@@ -215,7 +289,7 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
     if (full && (flags_aligned & 3u) == 3u) {
         if (threadIdx.x < 2 * kFlagLanes) {  // lanes 0..15: terminals, 16..31: truncations; 16 drones = 16 B each
             const uint32_t which = threadIdx.x / kFlagLanes, j = threadIdx.x % kFlagLanes;
-            const uint32_t bits = (uint32_t)(sh.masks[which][j >> 2] >> ((j & 3u) * 16u)) & 0xFFFFu;
+            const uint32_t bits = (uint32_t)(sh.masks[parity][which][j >> 2] >> ((j & 3u) * 16u)) & 0xFFFFu;
             const u4_t packed = {spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12)};
             unsigned char* base = which ? v.trunc : v.term;
             out_store(reinterpret_cast<u4_t*>(base + block_base) + j, packed);
@@ -307,52 +381,86 @@ template <int TASK, bool COMPACT>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
-    const uint32_t n = a.v.n, np = a.v.stride;
-    const uint32_t block_base = my_chunk() * kBlock;
-    const uint32_t i = block_base + threadIdx.x;
+    const uint32_t n = a.v.n, np = a.v.stride, n_pad = a.v.n_pad;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const bool valid = i < n;
-    // lanes [n, n_pad) exist in the planes and hold a valid reset state: they
-    // load and compute like the rest and store nothing.
-    Lane L;
-    load_lane<TASK>(a.v.planes, np, i, L);
-    float act[4];
-    {
-        const float4 av = valid ? reinterpret_cast<const float4*>(a.v.act)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        act[0] = av.x; act[1] = av.y; act[2] = av.z; act[3] = av.w;
-    }
-    StepOut out;
-    step_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, P.env_offset + i, a.gstep, out);
-    const bool done = valid && (out.oob || out.trunc);
-
-    if (valid) {
-        store_lane<TASK>(a.v.planes, np, i, L, out.target_changed);
-        out_store(&a.v.rew[i], out.reward);
-        if (done) {
-            float4 l0 = a.v.planes[kL0 * np + i], l1 = a.v.planes[kL1 * np + i];
-            fold_log(l0, l1, out);
-            a.v.planes[kL0 * np + i] = l0;
-            a.v.planes[kL1 * np + i] = l1;
+    float4* const tile = sh.obs_tile[threadIdx.x / kWave];
+    // This workgroup walks DRONE_STEP_TILES consecutive 256-drone chunks. Lanes [n, n_pad) exist in the planes
+    // and hold a valid reset state: they load and compute like the rest and store nothing.
+    uint32_t block_base = my_chunk() * (uint32_t)(DRONE_STEP_TILES * kBlock);
+    RawLane<TASK> cur;
+    load_raw<TASK>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
+    if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[a.done_slot ^ 1u] = 0u;  // arm the next step launch's counter
+#pragma unroll
+    for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
+        const uint32_t i = block_base + threadIdx.x;
+        const bool valid = i < n;
+        RawLane<TASK> nxt;
+        const bool more = t + 1 < DRONE_STEP_TILES && block_base + kBlock < n_pad;  // workgroup-uniform
+        if (t + 1 < DRONE_STEP_TILES) {  // compile-time: the next chunk's loads are in flight while this one computes
+            const uint32_t j = min(i + kBlock, n_pad - kBlock + threadIdx.x);  // past the end: this chunk again (unused)
+            load_raw<TASK>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
         }
-    }
 
-    if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
-        const uint64_t m_done = __ballot(done);
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[a.done_slot ^ 1u] = 0u;  // arm the next step launch's counter
-        if (m_done != 0) {  // wave-uniform
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.v.done_count + a.done_slot, (uint32_t)__popcll(m_done));
-            base = __shfl(base, 0);
-            if (done) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
-                a.v.done_ids[base + rank] = i;
+        Lane L;
+        float act[4];
+        unpack_lane<TASK>(cur, L, act);
+        StepOut out;
+        step_any<TASK>(P, L, tile, act, P.env_offset + i, a.gstep, out);
+        const bool done = valid && (out.oob || out.trunc);
+
+        // Episode ends (~1 % of the lanes, but some lane in about half of the waves): the per-env log sums are a
+        // read-modify-write of two cold planes. Their loads go out FIRST, ahead of this lane's stores, and are
+        // consumed at the very end of the chunk: vmcnt retires in issue order, so a load issued behind the
+        // state stores could only be waited for together with the write acknowledgements of those (non-temporal,
+        // HBM-latency) stores — which stalled the wave, and through the barrier its whole workgroup (−10 % at 2^22 envs).
+        // No branch around the stores either (a join would merge the outstanding-access counts of both paths and
+        // force a full drain): the padding lanes [n, n_pad) own their plane slots and simply evolve like phantom
+        // envs; only the caller's buffers are exactly n long, and there the padding lanes' reward goes to a sink.
+        const bool ended = !DRONE_EXP_NO_LOG && (out.oob || out.trunc);  // padding lanes included: their log slots exist too
+        const bool log_lane = lane_bit(whole_lines(__ballot(ended), a.v.line_complete));   // this lane's log slots share a line with an ended episode's
+        const bool tgt_lane = lane_bit(whole_lines(__ballot(out.target_changed), a.v.line_complete));
+        float4 l0, l1;
+        if (log_lane) {
+            l0 = a.v.cold[i];
+            l1 = a.v.cold[np + i];
+        }
+        store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, tgt_lane);
+        out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], out.reward);
+
+        if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
+            const uint64_t m_done = __ballot(done);
+            if (m_done != 0) {  // wave-uniform
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.v.done_count + a.done_slot, (uint32_t)__popcll(m_done));
+                base = __shfl(base, 0);
+                if (done) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
+                    a.v.done_ids[base + rank] = i;
+                }
             }
         }
-    }
 
-    float o[DRONE_OBS_DIM_MAX];
-    obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
-    write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base);
+#if !DRONE_LOG_FOLD_LATE
+        if (log_lane) {
+            if (ended) fold_log(l0, l1, out);
+            a.v.cold[i] = l0;
+            a.v.cold[np + i] = l1;
+        }
+#endif
+        float o[DRONE_OBS_DIM_MAX];
+        obs_any<TASK>(P, L, tile, o);
+        write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base, (uint32_t)t & 1u);
+#if DRONE_LOG_FOLD_LATE
+        if (log_lane) {  // last of all: the two loads have been in flight since before the state stores
+            asm volatile("" : "+v"(l0.x), "+v"(l1.x));  // pins the fold down here (the optimiser would hoist it up to the loads and wait there)
+            if (ended) fold_log(l0, l1, out);
+            a.v.cold[i] = l0;
+            a.v.cold[np + i] = l1;
+        }
+#endif
+        if (!more) break;
+        cur = nxt;
+    }
 }
 
 // =====================================================================
@@ -368,9 +476,9 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     Lane L;
     L.episode = 0u;
     lane_reset<TASK>(P, L, P.env_offset + i);
-    store_lane<DRONE_TASK_WAYPOINT>(a.v.planes, np, i, L, true);  // every plane, the aux plane (wind / gate normal) included
-    a.v.planes[kL0 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    a.v.planes[kL1 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, true);  // every plane of this task's tile (the wind plane starts at the zeros of the allocation's memset)
+    a.v.cold[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a.v.cold[np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) a.v.rew[i] = 0.0f;
     if (a.v.done_count && i < 2) a.v.done_count[i] = 0u;
     float o[DRONE_OBS_DIM_MAX];
@@ -403,8 +511,8 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
     Lane L;
-    load_lane<TASK>(a.v.planes, np, i, L);
-    float4 l0 = a.v.planes[kL0 * np + i], l1 = a.v.planes[kL1 * np + i];
+    load_lane<TASK>(a.v.planes, a.v.n_pad, i, L);
+    float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
     float rsum = 0.0f;
     bool any_term = false, any_trunc = false, any_target = false;
@@ -419,13 +527,12 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         any_target |= out.target_changed;
         if (out.oob || out.trunc) fold_log(l0, l1, out);
     }
-    if (valid) {
-        store_lane<TASK>(a.v.planes, np, i, L, any_target);
-        out_store(&a.v.rew[i], rsum);
-        if (any_term || any_trunc) {
-            a.v.planes[kL0 * np + i] = l0;
-            a.v.planes[kL1 * np + i] = l1;
-        }
+    // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)));
+    out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], rsum);
+    if (lane_bit(whole_lines(__ballot(any_term || any_trunc), a.v.line_complete))) {
+        a.v.cold[i] = l0;
+        a.v.cold[np + i] = l1;
     }
     float o[DRONE_OBS_DIM_MAX];
     obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
@@ -452,17 +559,17 @@ __global__ __launch_bounds__(kBlock) void drone_fill_actions_kernel(StepArgs a, 
 // Wave reduction by __shfl_down, one partial row per workgroup; the host adds
 // the rows in workgroup order, so the result is reproducible run to run.
 // =====================================================================
-__global__ __launch_bounds__(kBlock) void drone_log_reduce_kernel(float4* __restrict__ planes, uint32_t n, uint32_t np,
+__global__ __launch_bounds__(kBlock) void drone_log_reduce_kernel(float4* __restrict__ cold, uint32_t n, uint32_t np,
                                                                   double* __restrict__ partials) {
     __shared__ double red[kWavesPerBlock][6];
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 l0 = planes[kL0 * np + i];
-        const float4 l1 = planes[kL1 * np + i];
+        const float4 l0 = cold[i];
+        const float4 l1 = cold[np + i];
         s[0] += l0.x; s[1] += l0.y; s[2] += l0.z; s[3] += l0.w; s[4] += l1.x; s[5] += l1.y;
         if (l1.x != 0.0f) {
-            planes[kL0 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            planes[kL1 * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            cold[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            cold[np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -501,6 +608,7 @@ hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
     const dim3 g(v.n_pad / kBlock), b(kBlock);
     if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(make_args(v, 0));
     else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(make_args(v, 0));
+    else if (task == DRONE_TASK_WAYPOINT) drone_reset_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(make_args(v, 0));  // its tiles carry the wind plane
     else drone_reset_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(make_args(v, 0));
     return hipGetLastError();
 }
@@ -508,7 +616,7 @@ hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s) {
     StepArgs a = make_args(v, gstep);
     a.done_slot = done_slot & 1u;
-    const dim3 g(grid_for(v.n)), b(kBlock);
+    const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
     const bool compact = v.done_ids != nullptr;
     if (task == DRONE_TASK_HOVER) {
         if (compact) drone_step_kernel<DRONE_TASK_HOVER, true><<<g, b, 0, s>>>(a);
@@ -545,7 +653,7 @@ hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid
     int g = (int)grid_for(v.n);
     if (g > max_grid) g = max_grid;
     *grid_out = g;
-    drone_log_reduce_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(v.planes, v.n, v.stride, partials);
+    drone_log_reduce_kernel<<<dim3(g), dim3(kBlock), 0, s>>>(v.cold, v.n, v.stride, partials);
     return hipGetLastError();
 }
 

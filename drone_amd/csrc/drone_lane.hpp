@@ -17,7 +17,7 @@ namespace drone {
 
 #define fma_(a, b, c) __builtin_fmaf((a), (b), (c))
 
-// the 17 integrated components
+// the state the integrator advances: 13 rigid-body components by RK4, 4 rotor speeds in closed form
 struct Dyn {
     float p[3], v[3], q[4], o[3], r[4];
 };
@@ -38,7 +38,15 @@ struct StepOut {
     float perf, score, ep_return, ep_len;
 };
 
-DRONE_FN float clampc(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+// SPEC.md §4 clampc: fminf(fmaxf(x, lo), hi) with C99 NaN semantics (a NaN x yields lo). v_med3_f32 returns
+// min3 when an operand is NaN, i.e. lo as well, and the median otherwise: one instruction instead of two.
+DRONE_FN float clampc(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return __builtin_fminf(__builtin_fmaxf(x, lo), hi);
+#endif
+}
 
 DRONE_FN float dot3(const float (&a)[3], const float (&b)[3]) { return fma_(a[0], b[0], fma_(a[1], b[1], a[2] * b[2])); }
 
@@ -49,68 +57,103 @@ DRONE_FN void unit3(const float (&e)[3], float (&out)[3]) {
     for (int i = 0; i < 3; i++) out[i] = e[i] * inv;
 }
 
-// SPEC.md §4. ct[i] = cmd_i * inv_tau; 56 operations (59 with wind).
+// SPEC.md §4: what the rotors feed into the rigid body at one instant — twice the thrust acceleration and
+// the three body torques over the inertia — from the rotor speeds at that instant. 18 operations.
+struct RotorIn {
+    float aT2, tx, ty, tz;
+};
+DRONE_FN RotorIn rotor_inputs(const KParams& P, const float (&r)[4]) {
+    const float q0 = r[0] * r[0], q1 = r[1] * r[1], q2 = r[2] * r[2], q3 = r[3] * r[3];
+    const float s01 = q0 + q1, s23 = q2 + q3;
+    RotorIn u;
+    u.aT2 = P.kT2_m * (s01 + s23);
+    u.tx = P.cx * (s01 - s23);
+    u.ty = P.cy * ((q1 + q2) - (q0 + q3));
+    u.tz = P.cz * ((q0 + q2) - (q1 + q3));
+    return u;
+}
+
+// SPEC.md §4: derivative of the 10 components (v, q, o) that feed back; dp = v needs no work. 34 operations (37 with wind).
+struct Body {
+    float v[3], q[4], o[3];
+};
 template <int TASK>
-DRONE_FN void deriv(const KParams& P, const Dyn& S, const float (&ct)[4], const float (&wind)[3], Dyn& D) {
+DRONE_FN void deriv(const KParams& P, const Body& S, const RotorIn& u, const float (&wind)[3], Body& D) {
     const float w = S.q[0], x = S.q[1], y = S.q[2], z = S.q[3];
     const float ox = S.o[0], oy = S.o[1], oz = S.o[2];
-    const float q0 = S.r[0] * S.r[0], q1 = S.r[1] * S.r[1], q2 = S.r[2] * S.r[2], q3 = S.r[3] * S.r[3];
-    const float s01 = q0 + q1, s23 = q2 + q3;
-    const float aT2 = P.kT2_m * (s01 + s23);
     const float zx = fma_(x, z, w * y);
     const float zy = fma_(y, z, -(w * x));
     const float zzh = 0.5f - fma_(x, x, y * y);
     if (TASK == DRONE_TASK_WAYPOINT) {
-        D.v[0] = fma_(aT2, zx, -(P.drag_m * (S.v[0] - wind[0])));
-        D.v[1] = fma_(aT2, zy, -(P.drag_m * (S.v[1] - wind[1])));
-        D.v[2] = fma_(-P.drag_m, S.v[2] - wind[2], fma_(aT2, zzh, -P.gravity));
+        D.v[0] = fma_(u.aT2, zx, -(P.drag_m * (S.v[0] - wind[0])));
+        D.v[1] = fma_(u.aT2, zy, -(P.drag_m * (S.v[1] - wind[1])));
+        D.v[2] = fma_(-P.drag_m, S.v[2] - wind[2], fma_(u.aT2, zzh, -P.gravity));
     } else {  // wind == 0 and v - 0 is exact (SPEC.md §4)
-        D.v[0] = fma_(aT2, zx, -(P.drag_m * S.v[0]));
-        D.v[1] = fma_(aT2, zy, -(P.drag_m * S.v[1]));
-        D.v[2] = fma_(-P.drag_m, S.v[2], fma_(aT2, zzh, -P.gravity));
+        D.v[0] = fma_(u.aT2, zx, -(P.drag_m * S.v[0]));
+        D.v[1] = fma_(u.aT2, zy, -(P.drag_m * S.v[1]));
+        D.v[2] = fma_(-P.drag_m, S.v[2], fma_(u.aT2, zzh, -P.gravity));
     }
-    D.o[0] = fma_(P.cx, s01 - s23, fma_(-P.gxi, oy * oz, -(P.kdx * ox)));
-    D.o[1] = fma_(P.cy, (q1 + q2) - (q0 + q3), fma_(-P.gyi, oz * ox, -(P.kdy * oy)));
-    D.o[2] = fma_(P.cz, (q0 + q2) - (q1 + q3), fma_(-P.gzi, ox * oy, -(P.kdz * oz)));
+    D.o[0] = fma_(-P.gxi, oy * oz, fma_(-P.kdx, ox, u.tx));
+    D.o[1] = fma_(-P.gyi, oz * ox, fma_(-P.kdy, oy, u.ty));
+    D.o[2] = fma_(-P.gzi, ox * oy, fma_(-P.kdz, oz, u.tz));
     D.q[0] = -fma_(x, ox, fma_(y, oy, z * oz));  // q (x) (0, omega) = 2 qdot; the 1/2 is in hq*
     D.q[1] = fma_(w, ox, fma_(y, oz, -(z * oy)));
     D.q[2] = fma_(w, oy, fma_(z, ox, -(x * oz)));
     D.q[3] = fma_(w, oz, fma_(x, oy, -(y * ox)));
-#pragma unroll
-    for (int i = 0; i < 4; i++) D.r[i] = fma_(-P.inv_tau, S.r[i], ct[i]);
-#pragma unroll
-    for (int i = 0; i < 3; i++) D.p[i] = S.v[i];
 }
 
-// one RK4 stage update over the 17 components; the quaternion rows use the hq* steps
+// one RK4 stage update over the 10 feedback components; the quaternion rows use the hq* steps
 #define DRONE_FOR_COMPONENTS(BODY)                                      \
-    _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(p, i, h_) }    \
     _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(v, i, h_) }    \
     _Pragma("unroll") for (int i = 0; i < 4; i++) { BODY(q, i, hq_) }   \
-    _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(o, i, h_) }    \
-    _Pragma("unroll") for (int i = 0; i < 4; i++) { BODY(r, i, h_) }
+    _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(o, i, h_) }
 
+// SPEC.md §4: one substep of size h. Rotor speeds relax to cmd exactly (first-order lag, constant command), so the
+// rotor inputs are known functions of time: evaluated at t, t + h/2 (stages 2 and 3 share it) and t + h.
 template <int TASK>
-DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&ct)[4], const float (&wind)[3]) {
-    Dyn k, A, acc;
+DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3]) {
+    float rh[4], rf[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float d = S.r[i] - cmd[i];
+        rh[i] = fma_(P.e_half, d, cmd[i]);
+        rf[i] = fma_(P.e_full, d, cmd[i]);
+    }
+    const RotorIn u0 = rotor_inputs(P, S.r), uh = rotor_inputs(P, rh), uf = rotor_inputs(P, rf);
+    Body B, k, A, acc;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { B.v[i] = S.v[i]; B.o[i] = S.o[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) B.q[i] = S.q[i];
+    float pacc[3];  // dp = v: sum of the stage velocities v1 + 2 v2 + 2 v3 + v4
     const float h_full = P.h, h_half = P.h_half, h_sixth = P.h_sixth;
     const float hq_full = P.hq, hq_half = P.hq_half, hq_sixth = P.hq_sixth;
-    deriv<TASK>(P, S, ct, wind, k);
-#define STAGE1(f, i, H) acc.f[i] = k.f[i]; A.f[i] = fma_(H##half, k.f[i], S.f[i]);
+    deriv<TASK>(P, B, u0, wind, k);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pacc[i] = B.v[i];
+#define STAGE1(f, i, H) acc.f[i] = k.f[i]; A.f[i] = fma_(H##half, k.f[i], B.f[i]);
     DRONE_FOR_COMPONENTS(STAGE1)
-    deriv<TASK>(P, A, ct, wind, k);
-#define STAGE2(f, i, H) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(H##half, k.f[i], S.f[i]);
+    deriv<TASK>(P, A, uh, wind, k);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pacc[i] = fma_(2.0f, A.v[i], pacc[i]);
+#define STAGE2(f, i, H) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(H##half, k.f[i], B.f[i]);
     DRONE_FOR_COMPONENTS(STAGE2)
-    deriv<TASK>(P, A, ct, wind, k);
-#define STAGE3(f, i, H) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(H##full, k.f[i], S.f[i]);
+    deriv<TASK>(P, A, uh, wind, k);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pacc[i] = fma_(2.0f, A.v[i], pacc[i]);
+#define STAGE3(f, i, H) acc.f[i] = fma_(2.0f, k.f[i], acc.f[i]); A.f[i] = fma_(H##full, k.f[i], B.f[i]);
     DRONE_FOR_COMPONENTS(STAGE3)
-    deriv<TASK>(P, A, ct, wind, k);
-#define STAGE4(f, i, H) acc.f[i] = acc.f[i] + k.f[i]; S.f[i] = fma_(H##sixth, acc.f[i], S.f[i]);
+    deriv<TASK>(P, A, uf, wind, k);
+#pragma unroll
+    for (int i = 0; i < 3; i++) S.p[i] = fma_(h_sixth, pacc[i] + A.v[i], S.p[i]);
+#define STAGE4(f, i, H) acc.f[i] = acc.f[i] + k.f[i]; S.f[i] = fma_(H##sixth, acc.f[i], B.f[i]);
     DRONE_FOR_COMPONENTS(STAGE4)
 #undef STAGE1
 #undef STAGE2
 #undef STAGE3
 #undef STAGE4
+#pragma unroll
+    for (int i = 0; i < 4; i++) S.r[i] = rf[i];
 }
 
 DRONE_FN float target_dist(const Lane& L) {
@@ -122,12 +165,16 @@ DRONE_FN float target_dist(const Lane& L) {
 template <int TASK = DRONE_TASK_HOVER>
 DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     const uint32_t b = rng_base(P.key_reset, env, L.episode);
+    // nine values from five draws: 16-bit halves, low half first (SPEC.md §6)
+    uint32_t u[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) u[k] = rng_draw(b, k);
     float t[3];
 #pragma unroll
     for (uint32_t i = 0; i < 3; i++) {
-        L.s.p[i] = P.spawn_extent * sym(rng_draw(b, i));
-        L.tgt[i] = P.target_extent * sym(rng_draw(b, 3u + i));
-        t[i] = P.tilt_init * sym(rng_draw(b, 6u + i));
+        L.s.p[i] = P.spawn_extent * s16(half16(u, i));
+        L.tgt[i] = P.target_extent * s16(half16(u, 3u + i));
+        t[i] = P.tilt_init * s16(half16(u, 6u + i));
     }
     const float n2 = fma_(t[0], t[0], fma_(t[1], t[1], fma_(t[2], t[2], 1.0f)));
     const float inv = 1.0f / sqrtf(n2);
@@ -154,8 +201,8 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
 
 // SPEC.md §2: the synthetic random policy.
 DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float (&a)[4]) {
-    const uint32_t b = rng_base(key_action, env, gstep);
-    const uint32_t h0 = rng_draw(b, 0u), h1 = rng_draw(b, 1u);
+    const uint32_t k = hash32(key_action ^ env);  // invariant over the steps of a fused rollout
+    const uint32_t h0 = hash32(k + (2u * gstep) * 0x9E3779B9u), h1 = hash32(k + (2u * gstep + 1u) * 0x9E3779B9u);
     a[0] = s16(h0 & 0xFFFFu);
     a[1] = s16(h0 >> 16);
     a[2] = s16(h1 & 0xFFFFu);
@@ -172,11 +219,11 @@ struct StepCtx {
 // SPEC.md §5 steps 1–4: actions, wind, RK4, renormalise, clamp, tick.
 template <int TASK>
 DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepCtx& ctx) {
-    float a[4], ct[4];
+    float a[4], cmd[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         a[i] = clampc(act[i], -1.0f, 1.0f);
-        ct[i] = (P.half_max_rpm * (a[i] + 1.0f)) * P.inv_tau;
+        cmd[i] = P.half_max_rpm * (a[i] + 1.0f);
     }
     ctx.a2 = fma_(a[0], a[0], fma_(a[1], a[1], fma_(a[2], a[2], a[3] * a[3])));
     ctx.prev_dist = 0.0f;
@@ -197,7 +244,7 @@ DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], u
         ctx.prev_dist = target_dist(L);
     }
 
-    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, ct, L.wind);
+    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind);
 
     {
         float* q = L.s.q;
@@ -209,8 +256,7 @@ DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], u
         for (int i = 0; i < 3; i++) L.s.v[i] = clampc(L.s.v[i], -P.max_vel, P.max_vel);
 #pragma unroll
         for (int i = 0; i < 3; i++) L.s.o[i] = clampc(L.s.o[i], -P.max_omega, P.max_omega);
-#pragma unroll
-        for (int i = 0; i < 4; i++) L.s.r[i] = __builtin_fminf(L.s.r[i] < 0.0f ? 0.0f : L.s.r[i], P.max_rpm);
+        // rotor speeds need no clamp: each stays between its old value and cmd in [0, max_rpm]
     }
     L.tick += 1u;
 }

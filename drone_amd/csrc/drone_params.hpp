@@ -21,9 +21,14 @@ namespace drone {
 
 enum Stream : uint32_t { kReset = 0, kAction = 1, kWind = 2, kWaypoint = 3 };
 
-// ---- device state: float4 planes, each [n_pad] (DESIGN.md "Data layout") ----
-// One lane reads/writes one float4 per plane: 16 B/lane, 1 KiB per
-// wave-instruction, fully coalesced.
+// ---- device state (DESIGN.md "Data layout") ----
+// One lane reads/writes one float4 per plane: 16 B/lane, 1 KiB per wave-instruction, fully coalesced.
+// The planes a step touches every time (P0..PT, + PW for tasks 1 and 3) are interleaved per 64-drone wave tile:
+//   hot[tile = i / 64][plane][lane = i % 64]      (float4 elements)
+// so a wave streams ONE contiguous 6-7 KiB piece instead of 6-7 separate 1-KiB pieces 2^k bytes apart (+3 % at 2^22
+// envs where nothing is cached, profiles/r02_baseline/stream_mix.txt; and one base address + immediate offsets
+// instead of seven 64-bit address computations). The two log planes are cold (touched when an episode ends) and stay
+// plain planes: cold[k][stride].
 enum Plane : int {
     kP0 = 0,    // pos.x pos.y pos.z vel.x
     kP1 = 1,    // vel.y vel.z q.w q.x
@@ -37,7 +42,7 @@ enum Plane : int {
     kNumPlanes = 9
 };
 
-// Everything a lane needs that is the same for all lanes: 56 words. Reaches
+// Everything a lane needs that is the same for all lanes: 57 words. Reaches
 // the lanes through the kernarg segment (scalar loads) or, with
 // -DDRONE_PARAMS_IN_LDS=1, staged HBM -> LDS once per workgroup and read by
 // broadcast ds_read (drone_kernels.hip).
@@ -48,7 +53,7 @@ struct KParams {
     float kT2_m, cx, cy, cz;
     float gxi, gyi, gzi;
     float kdx, kdy, kdz;
-    float drag_m, inv_tau, gravity;
+    float drag_m, e_half, e_full, gravity;  // e_*: rotor lag over half a substep / a substep, exp(-h / (2 tau)), exp(-h / tau)
     float half_max_rpm, hover_rpm, max_rpm, max_vel, max_omega;
     // observation scales
     float inv_max_vel, inv_max_omega, inv_max_rpm, inv_bound, half_inv_bound;
@@ -65,8 +70,23 @@ struct KParams {
     uint32_t env_offset;
     uint32_t agents;  // drones per swarm (task 2), else 1
 };
-static_assert(sizeof(KParams) == 56 * 4, "KParams is passed / staged as 56 words");
-constexpr int kParamWords = 56;
+constexpr uint32_t kTile = 64;  // drones per state tile = one wavefront
+// planes per hot tile: the aux plane (wind / gate normal) exists only for the tasks that use it
+DRONE_FN constexpr uint32_t hot_planes(int task) { return (task == DRONE_TASK_WAYPOINT || task == DRONE_TASK_RACE) ? 7u : 6u; }
+#ifndef DRONE_TILED_STATE  // 0: plain planes [plane][n_pad] (the round-1 layout; kept for A/B at equal placement)
+#define DRONE_TILED_STATE 1
+#endif
+// float4 element of plane `p` of drone `i` in the hot region (`n_pad`: drones the region is laid out for)
+DRONE_FN constexpr uint32_t hot_index(uint32_t planes_per_tile, uint32_t p, uint32_t i, uint32_t n_pad) {
+#if DRONE_TILED_STATE
+    return ((i / kTile) * planes_per_tile + p) * kTile + (i % kTile);
+#else
+    return p * n_pad + i;
+#endif
+}
+
+static_assert(sizeof(KParams) == 57 * 4, "KParams is passed / staged as 57 words");
+constexpr int kParamWords = 57;
 
 // ---- SPEC.md §2: counter RNG ----
 DRONE_FN uint32_t hash32(uint32_t x) {
@@ -83,6 +103,8 @@ DRONE_FN uint32_t rng_base(uint32_t key, uint32_t env, uint32_t ctr) {
 DRONE_FN uint32_t rng_draw(uint32_t base, uint32_t d) { return hash32(base + d * 0x85EBCA6Bu); }
 DRONE_FN float sym(uint32_t u) { return __builtin_fmaf(2.0f, (float)(u >> 8) * 5.9604645e-8f, -1.0f); }
 DRONE_FN float s16(uint32_t h) { return (float)((int)h - 32768) * 3.0517578125e-5f; }
+// j-th 16-bit half of a run of 32-bit draws, low half first
+DRONE_FN uint32_t half16(const uint32_t* u, uint32_t j) { return (j & 1u) ? (u[j >> 1] >> 16) : (u[j >> 1] & 0xFFFFu); }
 
 inline uint32_t stream_key(uint64_t seed, uint32_t stream) {
     return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) ^ (0x9E3779B9u * (stream + 1u))));
@@ -111,7 +133,8 @@ inline void derive_kparams(const DroneConfig& c, uint64_t seed, KParams& p) {
     p.kdy = c.k_ang_damp * inv_iyy;
     p.kdz = c.k_ang_damp * inv_izz;
     p.drag_m = c.k_drag * inv_mass;
-    p.inv_tau = 1.0f / c.motor_tau;
+    p.e_half = (float)exp(-0.5 * (double)p.h / (double)c.motor_tau);  // double exp, rounded once: the same libm on both sides
+    p.e_full = (float)exp(-(double)p.h / (double)c.motor_tau);
     p.gravity = c.gravity;
     p.half_max_rpm = 0.5f * c.max_rpm;
     p.hover_rpm = sqrtf((c.mass * c.gravity) / (4.0f * c.k_thrust));

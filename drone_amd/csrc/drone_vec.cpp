@@ -158,11 +158,11 @@ bool validate(const DroneConfig* c, int num_envs) {
         if (num_envs % A || c->env_offset % (uint32_t)A) { set_err("num_envs and env_offset must be multiples of agents_per_env (%d)", A); return false; }
         if (!(c->proximity_radius > 0.0f)) { set_err("proximity_radius must be positive"); return false; }
     }
-    {   // plane addressing in the kernels is 32-bit: kNumPlanes * stride must fit (DRONE_PLANE_PAD included)
+    {   // state addressing in the kernels is 32-bit: the hot region's n_pad x planes-per-tile float4 elements must fit
         const uint64_t n_pad = ((uint64_t)num_envs + kBlock - 1) / kBlock * kBlock;
-        if ((uint64_t)kNumPlanes * (n_pad + plane_pad_elems()) > 0xFFFFFFFFull) {
-            set_err("num_envs %d too large: %d planes x stride must fit 32-bit element indices (max about %llu envs per handle; shard further)",
-                    num_envs, (int)kNumPlanes, (unsigned long long)(0xFFFFFFFFull / kNumPlanes - kBlock));
+        if (n_pad * 7u > 0xFFFFFFFFull || 2u * (n_pad + plane_pad_elems()) > 0xFFFFFFFFull) {
+            set_err("num_envs %d too large: the state region must fit 32-bit element indices (max about %llu envs per handle; shard further)",
+                    num_envs, (unsigned long long)(0xFFFFFFFFull / 7u - kBlock));
             return false;
         }
     }
@@ -417,9 +417,13 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->own_stream = true;
     INIT_TRY(hipEventCreate(&v->ev0));
     INIT_TRY(hipEventCreate(&v->ev1));
-    INIT_TRY(hipMalloc((void**)&v->dv.planes, sizeof(float4) * (size_t)kNumPlanes * v->stride));
-    INIT_TRY(hipMemsetAsync(v->dv.planes, 0, sizeof(float4) * (size_t)kNumPlanes * v->stride, v->stream));
+    const size_t hot_elems = (size_t)v->n_pad * hot_planes(cfg->task), cold_elems = (size_t)2 * v->stride;
+    INIT_TRY(hipMalloc((void**)&v->dv.planes, sizeof(float4) * hot_elems));
+    INIT_TRY(hipMemsetAsync(v->dv.planes, 0, sizeof(float4) * hot_elems, v->stream));
+    INIT_TRY(hipMalloc((void**)&v->dv.cold, sizeof(float4) * cold_elems));
+    INIT_TRY(hipMemsetAsync(v->dv.cold, 0, sizeof(float4) * cold_elems, v->stream));
     INIT_TRY(hipMalloc((void**)&v->d_kp, sizeof(KParams)));
+    INIT_TRY(hipMalloc((void**)&v->dv.pad_sink, sizeof(float) * kBlock));
     INIT_TRY(hipMalloc((void**)&v->d_partials, sizeof(double) * 6 * kLogMaxGrid));
     INIT_TRY(hipHostMalloc((void**)&v->h_partials, sizeof(double) * 6 * kLogMaxGrid, hipHostMallocDefault));
     if (cfg->compact_done) {
@@ -466,6 +470,13 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->dv.n = (uint32_t)num_envs;
     v->dv.n_pad = v->n_pad;
     v->dv.stride = v->stride;
+    {   // Partial-line plane updates (ended episodes) cost an HBM read-modify-write each unless the Infinity Cache absorbs
+        // them: widen them to whole lines once a step touches more than twice its 256 MiB (measured cross-over between
+        // 2^20 and 2^22 envs, profiles/r02_ab/). DRONE_LINE_COMPLETE=0/1 forces it.
+        const char* e = getenv("DRONE_LINE_COMPLETE");
+        const size_t touched = n * (sizeof(float4) * (2 * hot_planes(cfg->task) - 1) + (size_t)drone_obs_dim(cfg->task) * 4 + 16 + 6);
+        v->dv.line_complete = (e && *e) ? (atoi(e) != 0) : (touched > ((size_t)512 << 20));
+    }
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
@@ -539,7 +550,9 @@ void drone_vec_close(DroneVec* v) {
     for (int i = 0; i < 5; i++)
         if (v->registered[i]) (void)hipHostUnregister(v->registered_ptr[i]);
     (void)hipFree(v->dv.planes);
+    (void)hipFree(v->dv.cold);
     (void)hipFree(v->d_kp);
+    (void)hipFree(v->dv.pad_sink);
     (void)hipFree(v->d_partials);
     if (v->h_partials) (void)hipHostFree(v->h_partials);
     (void)hipFree(v->dv.done_ids);
@@ -643,25 +656,69 @@ void drone_vec_clear_status(DroneVec* v) {
 int drone_vec_num_envs(const DroneVec* v) { return v ? v->n : 0; }
 
 // ---- AoS import / export (tests, checkpoints): plain copies + host repack ----
+namespace {
+
+// host image of the tiles that cover envs [first, first + count) plus the matching pieces of the two cold planes
+struct StateImage {
+    uint32_t nph, tile0, ntiles, first;
+    std::vector<float4> hot, cold;  // hot: the covered tiles, laid out like the device region but for ntiles * 64 drones; cold: [2][count]
+    float4& at(uint32_t plane, uint32_t env) { return hot[hot_index(nph, plane, env - tile0 * kTile, ntiles * kTile)]; }
+};
+
+// copy the covered part of the hot region between the device and the image (one piece when tiled, one per plane otherwise)
+bool image_copy(DroneVec* v, StateImage& im, bool to_device) {
+#if DRONE_TILED_STATE
+    float4* dev = v->dv.planes + (size_t)im.tile0 * im.nph * kTile;
+    if (to_device) HIP_TRY(hipMemcpyAsync(dev, im.hot.data(), sizeof(float4) * im.hot.size(), hipMemcpyHostToDevice, v->stream), return false);
+    else HIP_TRY(hipMemcpyAsync(im.hot.data(), dev, sizeof(float4) * im.hot.size(), hipMemcpyDeviceToHost, v->stream), return false);
+#else
+    const size_t w = (size_t)im.ntiles * kTile;
+    for (uint32_t p = 0; p < im.nph; p++) {
+        float4* dev = v->dv.planes + (size_t)p * v->n_pad + (size_t)im.tile0 * kTile;
+        float4* host = im.hot.data() + (size_t)p * w;
+        if (to_device) HIP_TRY(hipMemcpyAsync(dev, host, sizeof(float4) * w, hipMemcpyHostToDevice, v->stream), return false);
+        else HIP_TRY(hipMemcpyAsync(host, dev, sizeof(float4) * w, hipMemcpyDeviceToHost, v->stream), return false);
+    }
+#endif
+    return true;
+}
+
+bool image_fetch(DroneVec* v, int first, int count, StateImage& im) {
+    im.nph = hot_planes(v->cfg.task);
+    im.first = (uint32_t)first;
+    im.tile0 = (uint32_t)first / kTile;
+    im.ntiles = ((uint32_t)(first + count) + kTile - 1) / kTile - im.tile0;
+    im.hot.resize((size_t)im.ntiles * im.nph * kTile);
+    im.cold.resize((size_t)2 * count);
+    if (count == 0) return true;
+    if (!image_copy(v, im, false)) return false;
+    for (int k = 0; k < 2; k++)
+        HIP_TRY(hipMemcpyAsync(im.cold.data() + (size_t)k * count, v->dv.cold + (size_t)k * v->stride + first, sizeof(float4) * count, hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);
+    return true;
+}
+
+}  // namespace
+
 int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) {
     Entry in(v);
     if (!in) return -1;
     if (!rows || first < 0 || count < 0 || first + count > v->n) { set_err("get_state: bad range"); return -1; }
-    std::vector<float4> tmp((size_t)kNumPlanes * count);
-    for (int p = 0; p < kNumPlanes; p++)
-        HIP_TRY(hipMemcpyAsync(tmp.data() + (size_t)p * count, v->dv.planes + (size_t)p * v->stride + first, sizeof(float4) * count, hipMemcpyDeviceToHost, v->stream), return -1);
-    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    StateImage im;
+    if (!image_fetch(v, first, count, im)) return -1;
     auto u = [](float f) { uint32_t x; memcpy(&x, &f, 4); return x; };
-    for (int i = 0; i < count; i++) {
-        const float4 a = tmp[(size_t)kP0 * count + i], b = tmp[(size_t)kP1 * count + i], c = tmp[(size_t)kP2 * count + i];
-        const float4 d = tmp[(size_t)kP3 * count + i], e = tmp[(size_t)kP4 * count + i], t = tmp[(size_t)kPT * count + i];
-        const float4 w = tmp[(size_t)kPW * count + i], l0 = tmp[(size_t)kL0 * count + i], l1 = tmp[(size_t)kL1 * count + i];
-        DroneStateRow& r = rows[i];
+    const bool aux = im.nph == 7;
+    for (int k = 0; k < count; k++) {
+        const uint32_t e = (uint32_t)(first + k);
+        const float4 a = im.at(kP0, e), b = im.at(kP1, e), c = im.at(kP2, e), d = im.at(kP3, e), ee = im.at(kP4, e), t = im.at(kPT, e);
+        const float4 w = aux ? im.at(kPW, e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 l0 = im.cold[k], l1 = im.cold[(size_t)count + k];
+        DroneStateRow& r = rows[k];
         r.pos[0] = a.x; r.pos[1] = a.y; r.pos[2] = a.z; r.vel[0] = a.w;
         r.vel[1] = b.x; r.vel[2] = b.y; r.quat[0] = b.z; r.quat[1] = b.w;
         r.quat[2] = c.x; r.quat[3] = c.y; r.omega[0] = c.z; r.omega[1] = c.w;
         r.omega[2] = d.x; r.rpm[0] = d.y; r.rpm[1] = d.z; r.rpm[2] = d.w;
-        r.rpm[3] = e.x; r.ep_return = e.y; r.tick = u(e.z); r.score_count = u(e.w);
+        r.rpm[3] = ee.x; r.ep_return = ee.y; r.tick = u(ee.z); r.score_count = u(ee.w);
         r.target[0] = t.x; r.target[1] = t.y; r.target[2] = t.z; r.episode = u(t.w);
         r.wind[0] = w.x; r.wind[1] = w.y; r.wind[2] = w.z;
         r.perf_sum = l0.x; r.score_sum = l0.y; r.ret_sum = l0.z; r.len_sum = l0.w;
@@ -674,22 +731,28 @@ int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int c
     Entry in(v);
     if (!in) return -1;
     if (!rows || first < 0 || count < 0 || first + count > v->n) { set_err("set_state: bad range"); return -1; }
-    std::vector<float4> tmp((size_t)kNumPlanes * count);
+    if (count == 0) return 0;
+    // the tiles at the edges of the range also hold neighbours: fetch, patch the rows, write the tiles back
+    StateImage im;
+    if (!image_fetch(v, first, count, im)) return -1;
     auto f = [](uint32_t x) { float y; memcpy(&y, &x, 4); return y; };
-    for (int i = 0; i < count; i++) {
-        const DroneStateRow& r = rows[i];
-        tmp[(size_t)kP0 * count + i] = make_float4(r.pos[0], r.pos[1], r.pos[2], r.vel[0]);
-        tmp[(size_t)kP1 * count + i] = make_float4(r.vel[1], r.vel[2], r.quat[0], r.quat[1]);
-        tmp[(size_t)kP2 * count + i] = make_float4(r.quat[2], r.quat[3], r.omega[0], r.omega[1]);
-        tmp[(size_t)kP3 * count + i] = make_float4(r.omega[2], r.rpm[0], r.rpm[1], r.rpm[2]);
-        tmp[(size_t)kP4 * count + i] = make_float4(r.rpm[3], r.ep_return, f(r.tick), f(r.score_count));
-        tmp[(size_t)kPT * count + i] = make_float4(r.target[0], r.target[1], r.target[2], f(r.episode));
-        tmp[(size_t)kPW * count + i] = make_float4(r.wind[0], r.wind[1], r.wind[2], 0.0f);
-        tmp[(size_t)kL0 * count + i] = make_float4(r.perf_sum, r.score_sum, r.ret_sum, r.len_sum);
-        tmp[(size_t)kL1 * count + i] = make_float4(r.n_sum, r.oob_sum, 0.0f, 0.0f);
+    const bool aux = im.nph == 7;
+    for (int k = 0; k < count; k++) {
+        const uint32_t e = (uint32_t)(first + k);
+        const DroneStateRow& r = rows[k];
+        im.at(kP0, e) = make_float4(r.pos[0], r.pos[1], r.pos[2], r.vel[0]);
+        im.at(kP1, e) = make_float4(r.vel[1], r.vel[2], r.quat[0], r.quat[1]);
+        im.at(kP2, e) = make_float4(r.quat[2], r.quat[3], r.omega[0], r.omega[1]);
+        im.at(kP3, e) = make_float4(r.omega[2], r.rpm[0], r.rpm[1], r.rpm[2]);
+        im.at(kP4, e) = make_float4(r.rpm[3], r.ep_return, f(r.tick), f(r.score_count));
+        im.at(kPT, e) = make_float4(r.target[0], r.target[1], r.target[2], f(r.episode));
+        if (aux) im.at(kPW, e) = make_float4(r.wind[0], r.wind[1], r.wind[2], 0.0f);
+        im.cold[k] = make_float4(r.perf_sum, r.score_sum, r.ret_sum, r.len_sum);
+        im.cold[(size_t)count + k] = make_float4(r.n_sum, r.oob_sum, 0.0f, 0.0f);
     }
-    for (int p = 0; p < kNumPlanes; p++)
-        HIP_TRY(hipMemcpyAsync(v->dv.planes + (size_t)p * v->stride + first, tmp.data() + (size_t)p * count, sizeof(float4) * count, hipMemcpyHostToDevice, v->stream), return -1);
+    if (!image_copy(v, im, true)) return -1;
+    for (int k = 0; k < 2; k++)
+        HIP_TRY(hipMemcpyAsync(v->dv.cold + (size_t)k * v->stride + first, im.cold.data() + (size_t)k * count, sizeof(float4) * count, hipMemcpyHostToDevice, v->stream), return -1);
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     return 0;
 }

@@ -41,7 +41,7 @@ typedef struct Params {
     float kT2_m, cx, cy, cz;
     float gxi, gyi, gzi;
     float kdx, kdy, kdz;
-    float drag_m, inv_tau;
+    float drag_m, e_half, e_full;
     float half_max_rpm, hover_rpm;
     float inv_max_vel, inv_max_omega, inv_max_rpm;
     float inv_bound, half_inv_bound;
@@ -74,7 +74,8 @@ static inline void params_derive(const DroneConfig* c, Params* p) {
     p->kdy = c->k_ang_damp * inv_iyy;
     p->kdz = c->k_ang_damp * inv_izz;
     p->drag_m = c->k_drag * inv_mass;
-    p->inv_tau = 1.0f / c->motor_tau;
+    p->e_half = (float)exp(-0.5 * (double)p->h / (double)c->motor_tau);
+    p->e_full = (float)exp(-(double)p->h / (double)c->motor_tau);
     p->half_max_rpm = 0.5f * c->max_rpm;
     p->hover_rpm = sqrtf((c->mass * c->gravity) / (4.0f * c->k_thrust));
     p->inv_max_vel = 1.0f / c->max_vel;
@@ -117,8 +118,9 @@ static inline float fmin_(float a, float b) { return (a <= b || b != b) ? a : b;
 static inline float clampc(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 
 static inline void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float a[4]) {
-    uint32_t b = rng_base(key_action, env, gstep);
-    uint32_t h0 = rng_draw(b, 0), h1 = rng_draw(b, 1);
+    const uint32_t k = hash32(key_action ^ env);
+    const uint32_t h0 = hash32(k + (2u * gstep) * 0x9E3779B9u);
+    const uint32_t h1 = hash32(k + (2u * gstep + 1u) * 0x9E3779B9u);
     a[0] = s16(h0 & 0xFFFFu);
     a[1] = s16(h0 >> 16);
     a[2] = s16(h1 & 0xFFFFu);
@@ -129,7 +131,7 @@ typedef struct Log {
     float perf, score, episode_return, episode_length, n, oob;
 } Log;
 
-/* SPEC.md §3: the 17 integrated components. */
+/* SPEC.md §3: pos, vel, quat, omega advance by RK4; rpm in closed form. */
 typedef struct State {
     float pos[3], vel[3], quat[4], omega[3], rpm[4];
 } State;
@@ -156,73 +158,101 @@ typedef struct Drone {
     const uint32_t* gstep; /* vec-level step counter */
 } Drone;
 
-/* SPEC.md §4: deriv. ct[i] = cmd_i * inv_tau. */
-static inline void deriv(const Drone* env, const State* S, const float ct[4], State* D) {
+/* SPEC.md §4: rotor inputs at one instant: twice the thrust acceleration, torques over inertia. */
+typedef struct Rotor {
+    float aT2, tx, ty, tz;
+} Rotor;
+
+static inline Rotor rotor_inputs(const Params* p, const float rpm[4]) {
+    float q[4];
+    for (int i = 0; i < 4; i++) q[i] = rpm[i] * rpm[i];
+    const float s01 = q[0] + q[1];
+    const float s23 = q[2] + q[3];
+    Rotor u;
+    u.aT2 = p->kT2_m * (s01 + s23);
+    u.tx = p->cx * (s01 - s23);
+    u.ty = p->cy * ((q[1] + q[2]) - (q[0] + q[3]));
+    u.tz = p->cz * ((q[0] + q[2]) - (q[1] + q[3]));
+    return u;
+}
+
+/* SPEC.md §4: deriv of (vel, quat, omega) given the rotor inputs of that instant. Only those ten
+ * components of `D` are written; dpos = vel is handled by the caller, rpm in closed form. */
+static inline void deriv(const Drone* env, const State* S, const Rotor* u, State* D) {
     const DroneConfig* c = env->cfg;
     const Params* p = env->par;
     const float w = S->quat[0], x = S->quat[1], y = S->quat[2], z = S->quat[3];
     const float ox = S->omega[0], oy = S->omega[1], oz = S->omega[2];
-    float q[4];
-    for (int i = 0; i < 4; i++) q[i] = S->rpm[i] * S->rpm[i];
-    const float s01 = q[0] + q[1];
-    const float s23 = q[2] + q[3];
-    const float aT2 = p->kT2_m * (s01 + s23);
     const float zx = fmaf(x, z, w * y);
     const float zy = fmaf(y, z, -(w * x));
     const float zzh = 0.5f - fmaf(x, x, y * y);
-    D->vel[0] = fmaf(aT2, zx, -(p->drag_m * (S->vel[0] - env->wind[0])));
-    D->vel[1] = fmaf(aT2, zy, -(p->drag_m * (S->vel[1] - env->wind[1])));
-    D->vel[2] = fmaf(-p->drag_m, S->vel[2] - env->wind[2], fmaf(aT2, zzh, -c->gravity));
-    D->omega[0] = fmaf(p->cx, s01 - s23, fmaf(-p->gxi, oy * oz, -(p->kdx * ox)));
-    D->omega[1] = fmaf(p->cy, (q[1] + q[2]) - (q[0] + q[3]), fmaf(-p->gyi, oz * ox, -(p->kdy * oy)));
-    D->omega[2] = fmaf(p->cz, (q[0] + q[2]) - (q[1] + q[3]), fmaf(-p->gzi, ox * oy, -(p->kdz * oz)));
+    D->vel[0] = fmaf(u->aT2, zx, -(p->drag_m * (S->vel[0] - env->wind[0])));
+    D->vel[1] = fmaf(u->aT2, zy, -(p->drag_m * (S->vel[1] - env->wind[1])));
+    D->vel[2] = fmaf(-p->drag_m, S->vel[2] - env->wind[2], fmaf(u->aT2, zzh, -c->gravity));
+    D->omega[0] = fmaf(-p->gxi, oy * oz, fmaf(-p->kdx, ox, u->tx));
+    D->omega[1] = fmaf(-p->gyi, oz * ox, fmaf(-p->kdy, oy, u->ty));
+    D->omega[2] = fmaf(-p->gzi, ox * oy, fmaf(-p->kdz, oz, u->tz));
     D->quat[0] = -fmaf(x, ox, fmaf(y, oy, z * oz)); /* q (x) (0, omega) = 2 qdot; the 1/2 is in hq* */
     D->quat[1] = fmaf(w, ox, fmaf(y, oz, -(z * oy)));
     D->quat[2] = fmaf(w, oy, fmaf(z, ox, -(x * oz)));
     D->quat[3] = fmaf(w, oz, fmaf(x, oy, -(y * ox)));
-    for (int i = 0; i < 4; i++) D->rpm[i] = fmaf(-p->inv_tau, S->rpm[i], ct[i]);
-    for (int i = 0; i < 3; i++) D->pos[i] = S->vel[i];
 }
 
-#define NCOMP 17 /* State is 17 contiguous floats */
-
+#define BODY_FIRST 3  /* State components 3..12 are vel, quat, omega: the ones RK4 feeds back */
+#define BODY_LAST 12
 #define QUAT_FIRST 6 /* components 6..9 of State are the quaternion */
 #define QUAT_LAST 9
 
-static inline void rk4_substep(Drone* env, const float ct[4]) {
+/* SPEC.md §4: one substep. cmd[i] = commanded rotor speed, held over the step. */
+static inline void rk4_substep(Drone* env, const float cmd[4]) {
     const Params* p = env->par;
     State k, A, acc;
     float* S = (float*)&env->s;
     float* kk = (float*)&k;
     float* AA = (float*)&A;
     float* ac = (float*)&acc;
-    float H[NCOMP], Hh[NCOMP], H6[NCOMP];
-    for (int c = 0; c < NCOMP; c++) {
+    float H[13], Hh[13], H6[13];
+    for (int c = BODY_FIRST; c <= BODY_LAST; c++) {
         const int is_q = c >= QUAT_FIRST && c <= QUAT_LAST;
         H[c] = is_q ? p->hq : p->h;
         Hh[c] = is_q ? p->hq_half : p->h_half;
         H6[c] = is_q ? p->hq_sixth : p->h_sixth;
     }
-    deriv(env, &env->s, ct, &k);
-    for (int c = 0; c < NCOMP; c++) {
+    /* rotor speeds: exact first-order lag toward cmd, at t + h/2 and t + h */
+    float r_half[4], r_full[4];
+    for (int i = 0; i < 4; i++) {
+        const float d = env->s.rpm[i] - cmd[i];
+        r_half[i] = fmaf(p->e_half, d, cmd[i]);
+        r_full[i] = fmaf(p->e_full, d, cmd[i]);
+    }
+    const Rotor u0 = rotor_inputs(p, env->s.rpm), uh = rotor_inputs(p, r_half), uf = rotor_inputs(p, r_full);
+    float vsum[3]; /* v1 + 2 v2 + 2 v3 (+ v4 at the end): dpos = vel */
+    A = env->s;
+    deriv(env, &env->s, &u0, &k);
+    for (int i = 0; i < 3; i++) vsum[i] = env->s.vel[i];
+    for (int c = BODY_FIRST; c <= BODY_LAST; c++) {
         ac[c] = kk[c];
         AA[c] = fmaf(Hh[c], kk[c], S[c]);
     }
-    deriv(env, &A, ct, &k);
-    for (int c = 0; c < NCOMP; c++) {
+    deriv(env, &A, &uh, &k);
+    for (int i = 0; i < 3; i++) vsum[i] = fmaf(2.0f, A.vel[i], vsum[i]);
+    for (int c = BODY_FIRST; c <= BODY_LAST; c++) {
         ac[c] = fmaf(2.0f, kk[c], ac[c]);
         AA[c] = fmaf(Hh[c], kk[c], S[c]);
     }
-    deriv(env, &A, ct, &k);
-    for (int c = 0; c < NCOMP; c++) {
+    deriv(env, &A, &uh, &k);
+    for (int i = 0; i < 3; i++) vsum[i] = fmaf(2.0f, A.vel[i], vsum[i]);
+    for (int c = BODY_FIRST; c <= BODY_LAST; c++) {
         ac[c] = fmaf(2.0f, kk[c], ac[c]);
         AA[c] = fmaf(H[c], kk[c], S[c]);
     }
-    deriv(env, &A, ct, &k);
-    for (int c = 0; c < NCOMP; c++) {
+    deriv(env, &A, &uf, &k);
+    for (int i = 0; i < 3; i++) env->s.pos[i] = fmaf(p->h_sixth, vsum[i] + A.vel[i], env->s.pos[i]);
+    for (int c = BODY_FIRST; c <= BODY_LAST; c++) {
         ac[c] = ac[c] + kk[c];
         S[c] = fmaf(H6[c], ac[c], S[c]);
     }
+    for (int i = 0; i < 4; i++) env->s.rpm[i] = r_full[i];
 }
 
 static inline float target_dist(const Drone* env) {
@@ -277,11 +307,17 @@ static inline void unit3(const float e[3], float out[3]) {
 static inline void reset_state(Drone* env) {
     const DroneConfig* c = env->cfg;
     const uint32_t b = rng_base(env->keys[STREAM_RESET], env->env_id, env->episode);
+    /* nine values from five 32-bit draws, 16 bits each, low half first */
+    float val[9];
+    for (uint32_t j = 0; j < 9; j++) {
+        const uint32_t u = rng_draw(b, j / 2u);
+        val[j] = s16((j & 1u) ? (u >> 16) : (u & 0xFFFFu));
+    }
     float t[3];
     for (uint32_t i = 0; i < 3; i++) {
-        env->s.pos[i] = c->spawn_extent * sym(rng_draw(b, i));
-        env->target[i] = c->target_extent * sym(rng_draw(b, 3 + i));
-        t[i] = c->tilt_init * sym(rng_draw(b, 6 + i));
+        env->s.pos[i] = c->spawn_extent * val[i];
+        env->target[i] = c->target_extent * val[3 + i];
+        t[i] = c->tilt_init * val[6 + i];
     }
     const float n2 = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], 1.0f)));
     const float inv = 1.0f / sqrtf(n2);
@@ -331,11 +367,10 @@ static inline void step_integrate(Drone* env) {
     const DroneConfig* c = env->cfg;
     const Params* p = env->par;
     State* s = &env->s;
-    float a[4], ct[4];
+    float a[4], cmd[4];
     for (int i = 0; i < 4; i++) {
         a[i] = clampc(env->actions[i], -1.0f, 1.0f);
-        const float cmd = p->half_max_rpm * (a[i] + 1.0f);
-        ct[i] = cmd * p->inv_tau;
+        cmd[i] = p->half_max_rpm * (a[i] + 1.0f);
     }
     env->scratch_a2 = fmaf(a[0], a[0], fmaf(a[1], a[1], fmaf(a[2], a[2], a[3] * a[3])));
     env->scratch_prev_dist = 0.0f;
@@ -353,7 +388,7 @@ static inline void step_integrate(Drone* env) {
         for (int i = 0; i < 3; i++) env->scratch_p0[i] = s->pos[i];
         env->scratch_prev_dist = target_dist(env);
     }
-    for (int k = 0; k < c->substeps; k++) rk4_substep(env, ct);
+    for (int k = 0; k < c->substeps; k++) rk4_substep(env, cmd);
     {
         float* q = s->quat;
         const float n2 = fmaf(q[0], q[0], fmaf(q[1], q[1], fmaf(q[2], q[2], q[3] * q[3])));
@@ -361,7 +396,7 @@ static inline void step_integrate(Drone* env) {
         for (int i = 0; i < 4; i++) q[i] = q[i] * sc;
         for (int i = 0; i < 3; i++) s->vel[i] = clampc(s->vel[i], -c->max_vel, c->max_vel);
         for (int i = 0; i < 3; i++) s->omega[i] = clampc(s->omega[i], -c->max_omega, c->max_omega);
-        for (int i = 0; i < 4; i++) s->rpm[i] = fmin_(s->rpm[i] < 0.0f ? 0.0f : s->rpm[i], c->max_rpm);
+        /* rotor speeds stay between their old value and cmd, both in [0, max_rpm]: no clamp */
     }
     env->tick += 1;
 }

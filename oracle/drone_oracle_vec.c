@@ -272,10 +272,10 @@ uint32_t oracle_stream_key(uint64_t seed, uint32_t stream) { return stream_key(s
 uint32_t oracle_rng_draw(uint32_t key, uint32_t env, uint32_t ctr, uint32_t d) {
     return rng_draw(rng_base(key, env, ctr), d);
 }
-void oracle_params_derive(const DroneConfig* c, float* out31) {
+void oracle_params_derive(const DroneConfig* c, float* out32) {
     Params p;
     params_derive(c, &p);
-    memcpy(out31, &p, sizeof(Params));
+    memcpy(out32, &p, sizeof(Params));
 }
 int oracle_omp_max_threads(void) {
 #ifdef _OPENMP

@@ -88,7 +88,7 @@ def default_config(task=0, **overrides):
 
 
 def params(cfg):
-    out = np.zeros(31, dtype=np.float32)
+    out = np.zeros(32, dtype=np.float32)
     lib().oracle_params_derive(C.byref(cfg), out.ctypes.data)
     return out
 

@@ -21,8 +21,10 @@ def rot(q):
     return R
 
 
-def deriv(c, S, cmd, wind):
-    p, v, q, o, r = S
+def deriv(c, S, r, wind):
+    """Rigid-body derivative at rotor speeds r (the rotors are not part of the RK4 system: their first-order
+    lag toward the held command is integrated exactly, SPEC.md §4)."""
+    p, v, q, o = S
     f = c["k_thrust"] * r * r
     T = f.sum(1)
     tx = c["arm_xy"] * ((f[:, 0] + f[:, 1]) - (f[:, 2] + f[:, 3]))
@@ -37,18 +39,19 @@ def deriv(c, S, cmd, wind):
     w, x, y, z = q.T
     ox, oy, oz = o.T
     dq = 0.5 * np.stack([-x * ox - y * oy - z * oz, w * ox + y * oz - z * oy, w * oy + z * ox - x * oz, w * oz + x * oy - y * ox], 1)
-    dr = (cmd - r) / c["motor_tau"]
-    return [v.copy(), dv, dq, do, dr]
+    return [v.copy(), dv, dq, do]
 
 
-def rk4(c, S, cmd, wind):
+def rk4(c, S5, cmd, wind):
     h = c["h"]
+    S, r0 = S5[:4], S5[4]
+    rotor = lambda t: cmd + (r0 - cmd) * np.exp(-t / c["motor_tau"])
     add = lambda A, k, s: [a + s * b for a, b in zip(A, k)]
-    k1 = deriv(c, S, cmd, wind)
-    k2 = deriv(c, add(S, k1, h / 2), cmd, wind)
-    k3 = deriv(c, add(S, k2, h / 2), cmd, wind)
-    k4 = deriv(c, add(S, k3, h), cmd, wind)
-    return [s + h / 6 * (a + 2 * b + 2 * d + e) for s, a, b, d, e in zip(S, k1, k2, k3, k4)]
+    k1 = deriv(c, S, rotor(0.0), wind)
+    k2 = deriv(c, add(S, k1, h / 2), rotor(h / 2), wind)
+    k3 = deriv(c, add(S, k2, h / 2), rotor(h / 2), wind)
+    k4 = deriv(c, add(S, k3, h), rotor(h), wind)
+    return [s + h / 6 * (a + 2 * b + 2 * d + e) for s, a, b, d, e in zip(S, k1, k2, k3, k4)] + [rotor(h)]
 
 
 def step(c, S, actions, wind):
@@ -125,8 +128,10 @@ RESET, ACTION, WIND, WAYPOINT = 0, 1, 2, 3
 
 
 def random_actions(seed, env, gstep):
-    b = rng_base(stream_key(seed, ACTION), env, gstep)
-    h0, h1 = rng_draw(b, 0), rng_draw(b, 1)
+    k = hash32(_u(stream_key(seed, ACTION)) ^ _u(env))
+    g = _u(gstep)
+    h0 = hash32((k + ((np.uint64(2) * g) & _M) * np.uint64(0x9E3779B9)) & _M)
+    h1 = hash32((k + ((np.uint64(2) * g + np.uint64(1)) & _M) * np.uint64(0x9E3779B9)) & _M)
     s16 = lambda h: (h.astype(np.int64) - 32768) / 32768.0
     return np.stack([s16(h0 & np.uint64(0xFFFF)), s16(h0 >> np.uint64(16)), s16(h1 & np.uint64(0xFFFF)), s16(h1 >> np.uint64(16))], 1)
 
@@ -138,7 +143,9 @@ def unit(e):
 def reset_draws(c, seed, env, episode, task):
     """SPEC.md §6 (+ §11 for the first gate normal): the fresh state of episode `episode` of global env `env`."""
     b = rng_base(stream_key(seed, RESET), env, episode)
-    u = [sym(rng_draw(b, k)) for k in range(9)]
+    draws = [rng_draw(b, k) for k in range(5)]  # nine 16-bit values from five draws, low half first
+    halves = [(draws[j // 2] >> np.uint64(16)) if j & 1 else (draws[j // 2] & np.uint64(0xFFFF)) for j in range(9)]
+    u = [(h.astype(np.int64) - 32768) / 32768.0 for h in halves]
     pos = c["spawn_extent"] * np.stack(u[0:3], 1)
     tgt = c["target_extent"] * np.stack(u[3:6], 1)
     t = c["tilt_init"] * np.stack(u[6:9], 1)

@@ -62,14 +62,14 @@ def test_lane_math_bit_exact_vs_oracle(lane, oracle, task, horizon, substeps):
 def test_kparams_match_oracle_params(lane, oracle):
     cfg = oracle.default_config(1, substeps=3, dt=0.02)
     want = oracle.params(cfg)
-    kp = np.zeros(56, np.uint32)
+    kp = np.zeros(57, np.uint32)
     lane.lane_host_kparams(C.byref(cfg), C.c_uint64(9), p(kp))
     f = kp.view(np.float32)
     # oracle Params order -> KParams word index
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27, 28, 35, 36, 43, 44, 45, 47]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 21, 25, 26, 27, 28, 29, 36, 37, 44, 45, 46, 48]
     assert_bits_equal(want, f[idx].copy(), "derived params")
     keys = [oracle.lib().oracle_stream_key(9, s) for s in range(4)]
-    assert list(kp[50:54]) == keys
+    assert list(kp[51:55]) == keys
 
 
 def test_random_configs_bit_exact(lane, oracle):

@@ -57,7 +57,8 @@ def test_random_policy_known_answers(oracle):
     for g in (0, 5, 2**31):
         a = v.fill_random_actions(gstep=g)
         for i in (0, 1, 100, 256):
-            h0, h1 = py_draw(key, off + i, g, 0), py_draw(key, off + i, g, 1)
+            k = py_hash32(key ^ (off + i))
+            h0, h1 = py_hash32((k + (2 * g) * 0x9E3779B9) & M32), py_hash32((k + (2 * g + 1) * 0x9E3779B9) & M32)
             want = [((h0 & 0xFFFF) - 32768) / 32768.0, ((h0 >> 16) - 32768) / 32768.0,
                     ((h1 & 0xFFFF) - 32768) / 32768.0, ((h1 >> 16) - 32768) / 32768.0]
             assert a[i].tolist() == want
@@ -75,9 +76,10 @@ def test_reset_known_answers(oracle):
     key = py_stream_key(seed, 0)
     f32 = np.float32
     for i in range(8):
-        u = [py_draw(key, off + i, 0, d) for d in range(9)]
-        # 2*u01 - 1 is exact in float32 (24-bit u01, power-of-two scale), so fma and mul+add agree
-        sym = [f32(f32(2.0) * (f32(x >> 8) * f32(2.0**-24)) - f32(1.0)) for x in u]
+        u = [py_draw(key, off + i, 0, d) for d in range(5)]
+        # nine 16-bit halves of five draws, low half first; (h - 32768) / 32768 is exact in float32
+        halves = [(u[j // 2] >> 16) if j & 1 else (u[j // 2] & 0xFFFF) for j in range(9)]
+        sym = [f32((h - 32768) / 32768.0) for h in halves]
         assert st["pos"][i].tolist() == [float(f32(cfg.spawn_extent) * s) for s in sym[0:3]]
         assert st["target"][i].tolist() == [float(f32(cfg.target_extent) * s) for s in sym[3:6]]
         t = [f32(cfg.tilt_init) * s for s in sym[6:9]]

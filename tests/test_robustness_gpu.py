@@ -129,7 +129,7 @@ def test_num_envs_beyond_32bit_plane_indexing_is_refused(hip):
     f = hip._fns
     cfg = hip.default_config(0)
     p = buf.ctypes.data
-    big = (1 << 32) // 9 + 4096  # 9 planes x stride no longer fits 32-bit element indices
+    big = (1 << 32) // 7 + 4096  # 7 planes per tile x n_pad no longer fits 32-bit element indices
     assert not f["drone_vec_init"](p, p, p, p, p, big, 0, C_byref(cfg))
     assert "too large" in hip.last_error()
 

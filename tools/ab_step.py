@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=128)
     ap.add_argument("--fresh", action="store_true")
     ap.add_argument("--ring", type=int, default=4)
+    ap.add_argument("--warm", type=int, default=150, help="untimed steps first (150: past the synchronised first episode ends)")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     import torch
@@ -77,7 +78,8 @@ def main():
     def make(name):
         fns, envs, _ = specs[name]
         os.environ.update(envs)
-        v = binding.DroneVec(a.envs, seed=0, task=task, device="cuda:0", fns=fns)
+        over = {k[4:]: (float(val) if "." in val or "e" in val else int(val)) for k, val in envs.items() if k.startswith("CFG_")}  # CFG_bound=1e6,CFG_horizon=1000000000
+        v = binding.DroneVec(a.envs, seed=0, task=task, device="cuda:0", fns=fns, **over)
         for k in envs:
             os.environ.pop(k, None)
         v._raw = []
@@ -98,7 +100,7 @@ def main():
 
     def timeit(v, ring):
         if a.mode == "step":
-            for k in range(20):
+            for k in range(a.warm):
                 v.bind_actions(ring[k % len(ring)])
                 v.step()
             torch.cuda.synchronize()

@@ -48,6 +48,49 @@ __global__ __launch_bounds__(BLOCK) void env_like(f4* __restrict__ state, const 
     __builtin_nontemporal_store(acc.x, &rew[i]);
 }
 
+// the same traffic with the real kernel's other two properties dialled in: VALU work between the loads and the
+// stores (FMAS dependent v_fma_f32 per lane, in 4 chains) and a cap on waves per SIMD (the real kernel holds 5)
+template <int FMAS, int WAVES, bool EARLY_STATE_STORE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WAVES))) void env_like_work(f4* __restrict__ state, const f4* __restrict__ act, f4* __restrict__ obs, float* __restrict__ rew, size_t n, float k) {
+    const unsigned nwg = gridDim.x, x = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned chunk = (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (blockIdx.x >> 3);
+    const size_t i = (size_t)chunk * 256 + threadIdx.x;
+    if (i >= n) return;
+    f4 s[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) s[p] = state[state_index<0>(n, i, p)];
+    const f4 a = act[i];
+    f4 acc = a;
+#pragma unroll
+    for (int p = 0; p < P; p++) acc += s[p];
+#pragma unroll 8
+    for (int j = 0; j < FMAS / 4; j++) {
+        acc.x = __builtin_fmaf(acc.x, k, 1.0f);
+        acc.y = __builtin_fmaf(acc.y, k, 1.0f);
+        acc.z = __builtin_fmaf(acc.z, k, 1.0f);
+        acc.w = __builtin_fmaf(acc.w, k, 1.0f);
+    }
+#pragma unroll
+    for (int p = 0; p < PW; p++) __builtin_nontemporal_store(s[p] + acc, &state[state_index<0>(n, i, p)]);
+    if (EARLY_STATE_STORE) {
+#pragma unroll 8
+        for (int j = 0; j < 64 / 4; j++) {
+            acc.x = __builtin_fmaf(acc.x, k, 1.0f);
+            acc.y = __builtin_fmaf(acc.y, k, 1.0f);
+            acc.z = __builtin_fmaf(acc.z, k, 1.0f);
+            acc.w = __builtin_fmaf(acc.w, k, 1.0f);
+        }
+    }
+    const size_t lane = threadIdx.x & 63, wave_base = i - lane;
+    f4* dst = obs + wave_base * 5;
+#pragma unroll
+    for (int kk = 0; kk < 5; kk++) __builtin_nontemporal_store(acc + (float)kk, &dst[kk * 64 + lane]);
+    __builtin_nontemporal_store(acc.x, &rew[i]);
+}
+
+template <int FMAS, int WAVES, bool EARLY = false>
+void run_work(const char* name, f4* state, f4* act, f4* obs, float* rew, size_t n, int reps);
+
 // persistent form: grid = a few workgroups per CU, each walks tiles with a stride
 template <int T, bool NT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void env_like_persistent(f4* __restrict__ state, const f4* __restrict__ act, f4* __restrict__ obs, float* __restrict__ rew, size_t n) {
@@ -136,6 +179,12 @@ void run_env_p(const char* name, const Bufs& B, size_t n, int reps, int wg_per_c
     report(name, n, time_us([&]() { env_like_persistent<T, NT, BLOCK><<<grid, BLOCK>>>(B.state, B.act, B.obs, B.rew, n); }, reps), 276.0);
 }
 
+template <int FMAS, int WAVES, bool EARLY>
+void run_work(const char* name, f4* state, f4* act, f4* obs, float* rew, size_t n, int reps) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    report(name, n, time_us([&]() { env_like_work<FMAS, WAVES, EARLY><<<grid, 256>>>(state, act, obs, rew, n, 0.999f); }, reps), 276.0);
+}
+
 int main(int argc, char** argv) {
     size_t sizes[16];
     int ns = 0;
@@ -173,6 +222,18 @@ int main(int argc, char** argv) {
         run_env<1024, true, 1024, true>("tiles of 1024, wg1024, xcd, nt", B, n, reps);
         run_env<64, true, 64, true>("tiles of 64, wg64, xcd, nt", B, n, reps);
         run_env<0, true, 64, true>("planes, wg64, xcd, nt", B, n, reps);
+        run_work<0, 8>("planes + 0 fma, <=8 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<0, 5>("planes + 0 fma, <=5 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<0, 4>("planes + 0 fma, <=4 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<0, 2>("planes + 0 fma, <=2 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<200, 8>("planes + 200 fma, <=8 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<200, 5>("planes + 200 fma, <=5 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<448, 8>("planes + 448 fma, <=8 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<448, 6>("planes + 448 fma, <=6 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<448, 5>("planes + 448 fma, <=5 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<448, 4>("planes + 448 fma, <=4 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<448, 5, true>("planes + 448 fma, <=5 waves, +64 fma before obs", B.state, B.act, B.obs, B.rew, n, reps);
+        run_work<640, 5>("planes + 640 fma, <=5 waves/SIMD", B.state, B.act, B.obs, B.rew, n, reps);
         run_env_p<256, true, 256>("tiles of 256, persistent 4 wg/CU, nt", B, n, reps, 4);
         run_env_p<256, true, 256>("tiles of 256, persistent 8 wg/CU, nt", B, n, reps, 8);
         run_env_p<0, true, 256>("planes, persistent 8 wg/CU, nt", B, n, reps, 8);
