@@ -24,6 +24,7 @@ struct DeviceView {
     float* rew;          // [n]
     unsigned char* term; // [n]
     unsigned char* trunc;// [n]
+    unsigned long long* stamps; // diagnostic builds only (-DDRONE_STAMPS=1): [waves][kStampSlots] clock stamps, else null
     float* pad_sink;     // [kBlock] floats: where the padding lanes [n, n_pad) of the last workgroup drop their reward
     uint32_t* done_ids;  // [n] or null
     uint32_t* done_count;// [2] ping-pong per step launch, or null
@@ -33,6 +34,7 @@ struct DeviceView {
 #define DRONE_BLOCK 256
 #endif
 constexpr int kBlock = DRONE_BLOCK;
+constexpr int kStampSlots = 10;  // -DDRONE_STAMPS=1: s_memtime at 8 points of the step kernel + s_memrealtime at entry and exit
 
 hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s);
 // done_slot: which done_count slot this launch adds to (compact_done); the kernel zeroes the other one for the next step launch

@@ -27,6 +27,9 @@
 
 // ---- tuning knobs (compile-time). Defaults are the measured best at equal
 // memory placement: DESIGN.md "Tuning log", profiles/r01_ab_*.txt ----
+#ifndef DRONE_PARAMS_GLOBAL  // 1: KParams read by scalar loads from the handle's HBM copy (constant address space) instead of by value in the kernarg segment: a 228-B shorter kernarg fetch ahead of the first state load
+#define DRONE_PARAMS_GLOBAL 0
+#endif
 #ifndef DRONE_PARAMS_IN_LDS  // 1: stage KParams HBM -> LDS per workgroup; 0: kernarg scalar loads (-2.4 % step, -13 % rollout)
 #define DRONE_PARAMS_IN_LDS 0
 #endif
@@ -61,6 +64,24 @@
 #endif
 #ifndef DRONE_EXP_NO_PT
 #define DRONE_EXP_NO_PT 0
+#endif
+
+// DIAGNOSTIC BUILD ONLY (tools/stamps.py): s_memtime stamps at the phase boundaries of the step kernel, one row per
+// wave, to see where a small shard's few microseconds go. Never timed as a whole: the stamps' fences forbid overlaps.
+#ifndef DRONE_STAMPS
+#define DRONE_STAMPS 0
+#endif
+#if DRONE_STAMPS
+#define DRONE_STAMP(k)                                                                                       \
+    do {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        stamp_[k] = t_;                                                                                      \
+    } while (0)
+#else
+#define DRONE_STAMP(k) do {} while (0)
 #endif
 
 #ifndef DRONE_ROLLOUT_MIN_WAVES  // __launch_bounds__ 2nd argument of the fused rollout kernel; 0 = unset
@@ -222,7 +243,7 @@ struct StepArgs {
     uint32_t gstep;
     uint32_t flags_aligned;  // bit0: terminals 16-B aligned, bit1: truncations 16-B aligned
     uint32_t done_slot;      // which of the two done-list counters this step launch adds to (the host alternates per STEP launch)
-#if !DRONE_PARAMS_IN_LDS
+#if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     KParams kp;              // constants by value: scalar loads from the kernarg segment
 #endif
 };
@@ -243,6 +264,9 @@ __device__ __forceinline__ const KParams& stage_params(KParams& sp, const uint32
     __syncthreads();
     return sp;
 }
+#elif DRONE_PARAMS_GLOBAL
+typedef const KParams __attribute__((address_space(4))) ConstKParams;  // constant address space: uniform loads become s_load
+#define DRONE_PARAMS(sh, a) (*(const KParams*)(ConstKParams*)(a).v.kp)
 #else
 #define DRONE_PARAMS(sh, a) ((a).kp)
 #endif
@@ -269,14 +293,25 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
         sh.masks[parity][0][wave] = m_term;
         sh.masks[parity][1][wave] = m_trunc;
     }
+    // Observation rows: the tile is private to this wave and a wave's LDS operations execute in order, so the
+    // transpose needs only compiler ordering (wave-scope fences) — no workgroup barrier on this path. Rows go in
+    // row-major ([lane][4*OBSV]: ds_write_b128, conflict-free at the 80-B row stride), come back flat, and leave as
+    // OBSV x 1 KiB contiguous stores per wave.
     float4* tile = sh.obs_tile[wave];
 #pragma unroll
-    for (int k = 0; k < OBSV; k++)  // row-major [lane][4*OBSV]: ds_write_b128, conflict-free at the 80-B row stride
-        tile[lane * OBSV + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    __syncthreads();
-
-    if (wave_base < n) {  // read the tile back flat: 5 x 1 KiB contiguous per wave
-        const uint32_t rows = n - wave_base < (uint32_t)kWave ? n - wave_base : (uint32_t)kWave;
+    for (int k = 0; k < OBSV; k++) tile[lane * OBSV + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (wave_base + kWave <= n) {  // a full wave (wave-uniform): all reads first, then the stores, no per-piece guards
+        float4* dst = reinterpret_cast<float4*>(v.obs + (size_t)wave_base * (4 * OBSV));
+        float4 piece[OBSV];
+#pragma unroll
+        for (int k = 0; k < OBSV; k++) piece[k] = tile[k * kWave + lane];
+#pragma unroll
+        for (int k = 0; k < OBSV; k++) out_store(&dst[k * kWave + lane], piece[k]);
+    } else if (wave_base < n) {  // the ragged last wave
+        const uint32_t rows = n - wave_base;
         float4* dst = reinterpret_cast<float4*>(v.obs + (size_t)wave_base * (4 * OBSV));
 #pragma unroll
         for (int k = 0; k < OBSV; k++) {
@@ -284,6 +319,10 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
             if (j < rows * OBSV) out_store(&dst[j], tile[j]);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads are done before the tile is written again
+    __builtin_amdgcn_wave_barrier();
+
+    __syncthreads();  // the flag bytes are assembled from all four waves' masks
 
     const bool full = block_base + kBlock <= n;  // workgroup-uniform
     if (full && (flags_aligned & 3u) == 3u) {
@@ -387,6 +426,11 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     // This workgroup walks DRONE_STEP_TILES consecutive 256-drone chunks. Lanes [n, n_pad) exist in the planes
     // and hold a valid reset state: they load and compute like the rest and store nothing.
     uint32_t block_base = my_chunk() * (uint32_t)(DRONE_STEP_TILES * kBlock);
+#if DRONE_STAMPS
+    unsigned long long stamp_[kStampSlots];
+    stamp_[8] = __builtin_amdgcn_s_memrealtime();
+#endif
+    DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
     load_raw<TASK>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[a.done_slot ^ 1u] = 0u;  // arm the next step launch's counter
@@ -403,9 +447,18 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
 
         Lane L;
         float act[4];
+        DRONE_STAMP(1);  // loads issued
         unpack_lane<TASK>(cur, L, act);
+#if DRONE_STAMPS
+        asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.r[3]), "v"(L.tgt[0]), "v"(act[0]));  // everything has landed
+#endif
+        DRONE_STAMP(2);  // data arrived
         StepOut out;
         step_any<TASK>(P, L, tile, act, P.env_offset + i, a.gstep, out);
+#if DRONE_STAMPS
+        asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.q[0]), "v"(out.reward));
+#endif
+        DRONE_STAMP(3);  // integrated, reward, reset
         const bool done = valid && (out.oob || out.trunc);
 
         // Episode ends (~1 % of the lanes, but some lane in about half of the waves): the per-env log sums are a
@@ -426,6 +479,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         }
         store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, tgt_lane);
         out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], out.reward);
+        DRONE_STAMP(4);  // state stores issued
 
         if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
             const uint64_t m_done = __ballot(done);
@@ -449,13 +503,23 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
 #endif
         float o[DRONE_OBS_DIM_MAX];
         obs_any<TASK>(P, L, tile, o);
+        DRONE_STAMP(5);  // observation math done
         write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base, (uint32_t)t & 1u);
+        DRONE_STAMP(6);  // LDS transpose, barrier, observation / flag stores issued
 #if DRONE_LOG_FOLD_LATE
         if (log_lane) {  // last of all: the two loads have been in flight since before the state stores
             asm volatile("" : "+v"(l0.x), "+v"(l1.x));  // pins the fold down here (the optimiser would hoist it up to the loads and wait there)
             if (ended) fold_log(l0, l1, out);
             a.v.cold[i] = l0;
             a.v.cold[np + i] = l1;
+        }
+#endif
+#if DRONE_STAMPS
+        DRONE_STAMP(7);  // log fold done
+        stamp_[9] = __builtin_amdgcn_s_memrealtime();
+        if (a.v.stamps && lane == 0) {
+            unsigned long long* row = a.v.stamps + (size_t)(i / kWave) * kStampSlots;
+            for (int k = 0; k < kStampSlots; k++) row[k] = stamp_[k];
         }
 #endif
         if (!more) break;
@@ -594,7 +658,7 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     a.gstep = gstep;
     a.done_slot = 0;
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
-#if !DRONE_PARAMS_IN_LDS
+#if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     a.kp = *v.kp_host;
 #endif
     return a;

@@ -424,6 +424,9 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     INIT_TRY(hipMemsetAsync(v->dv.cold, 0, sizeof(float4) * cold_elems, v->stream));
     INIT_TRY(hipMalloc((void**)&v->d_kp, sizeof(KParams)));
     INIT_TRY(hipMalloc((void**)&v->dv.pad_sink, sizeof(float) * kBlock));
+#if defined(DRONE_STAMPS) && DRONE_STAMPS  // diagnostic build (tools/stamps.py)
+    INIT_TRY(hipMalloc((void**)&v->dv.stamps, sizeof(unsigned long long) * kStampSlots * (v->n_pad / 64)));
+#endif
     INIT_TRY(hipMalloc((void**)&v->d_partials, sizeof(double) * 6 * kLogMaxGrid));
     INIT_TRY(hipHostMalloc((void**)&v->h_partials, sizeof(double) * 6 * kLogMaxGrid, hipHostMallocDefault));
     if (cfg->compact_done) {
@@ -553,6 +556,7 @@ void drone_vec_close(DroneVec* v) {
     (void)hipFree(v->dv.cold);
     (void)hipFree(v->d_kp);
     (void)hipFree(v->dv.pad_sink);
+    (void)hipFree(v->dv.stamps);
     (void)hipFree(v->d_partials);
     if (v->h_partials) (void)hipHostFree(v->h_partials);
     (void)hipFree(v->dv.done_ids);
@@ -789,6 +793,18 @@ int drone_vec_timer_stop(DroneVec* v, float* elapsed_ms) {
     HIP_TRY(hipEventElapsedTime(elapsed_ms, v->ev0, v->ev1), return -1);
     return 0;
 }
+
+#if defined(DRONE_STAMPS) && DRONE_STAMPS
+// diagnostic build only; not part of include/drone_vec.h
+int drone_debug_stamps(DroneVec* v, unsigned long long* out, int max_rows) {
+    Entry in(v);
+    if (!in || !v->dv.stamps) return -1;
+    const int rows = (int)(v->n_pad / 64) < max_rows ? (int)(v->n_pad / 64) : max_rows;
+    HIP_TRY(hipMemcpyAsync(out, v->dv.stamps, sizeof(unsigned long long) * kStampSlots * rows, hipMemcpyDeviceToHost, v->stream), return -1);
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    return rows;
+}
+#endif
 
 // ---- host-boundary all-gather (RCCL) ----
 int drone_gather_unique_id(unsigned char* id) {

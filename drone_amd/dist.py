@@ -82,8 +82,11 @@ class PipelinedGather:
     On CPU tensors (gloo) the same code runs synchronously.
     """
 
-    def __init__(self, vec, total_envs, obs_dim, group=None):
+    def __init__(self, vec, total_envs, obs_dim, group=None, launch=None):
         self.vec = vec
+        # what one "step" launches on the env: vec.step() by default; e.g. `lambda: vec.rollout(128)` pipelines the
+        # horizon gather of one fused rollout behind the next rollout's kernel (the device-side policy needs no observations)
+        self.launch = launch if launch is not None else vec.step
         first = (vec.observations, vec.rewards, vec.terminals, vec.truncations)
         second = tuple(torch.empty_like(t) for t in first)
         self.sets = [first, second]
@@ -103,14 +106,14 @@ class PipelinedGather:
         outs = self.sets[i]
         if not self.cuda:
             self.vec.bind_outputs(*outs)
-            self.vec.step()
+            self.launch()
             return self.gathers[i](*outs), None
         main = torch.cuda.current_stream(outs[0].device)
         if hasattr(self.vec, "use_torch_stream"):
             self.vec.use_torch_stream()  # launch on the stream the events below are recorded on (a no-op while it is unchanged)
         main.wait_event(self.done[i])  # the gather that last read this set (two steps ago) has finished
         self.vec.bind_outputs(*outs)
-        self.vec.step()
+        self.launch()
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self.comm):

@@ -11,7 +11,7 @@ OUT="$R/gpurun_out/$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--cpu-seconds 0 --no-extras $*"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" --steps 2000 --warmup 200 $ARGS > "$OUT/stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/bench.py" ${STEPS_ARGS:---steps 2000 --warmup 200} $ARGS > "$OUT/stats.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" --steps 100 --warmup 10 $ARGS > "$OUT/pmc_fetch.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" --steps 100 --warmup 10 $ARGS > "$OUT/pmc_write.log" 2>&1
 grep "^{" "$OUT/stats.log" | tail -1 > "$OUT/bench_line_under_rocprof.json"   # bench.py's own line while profiled
