@@ -88,6 +88,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "drone_config_default": (None, [C.POINTER(DroneConfig), C.c_int]),
     "drone_obs_dim": (C.c_int, [C.c_int]),
+    "drone_device_count": (C.c_int, []),
     "drone_vec_init": (_P, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(DroneConfig)]),
     "drone_vec_reset": (None, [_P, C.c_uint64]),
     "drone_vec_step": (None, [_P]),

@@ -389,17 +389,21 @@ __device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float4*
     }
 }
 
-// which 256-drone chunk this workgroup owns
-__device__ __forceinline__ uint32_t my_chunk() {
+// which 256-drone chunk this workgroup owns. `order` (a launch argument, chosen by the host from the step's
+// footprint; DeviceView::order) — bit 0: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the
+// envs instead of being dealt round-robin over one global sweep; bit 1 (odd steps only): sweep in reverse, so the
+// lines touched last in one step are the first touched in the next and are still in the Infinity Cache.
+// Bijective for any grid size; a speed choice only (profiles/r02_ab/ab_zz_*.txt, ab_order_*.txt).
+__device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep) {
+    uint32_t c = blockIdx.x;
 #if DRONE_XCD_REMAP
-    // Workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 labels the
-    // workgroups that share an XCD (and its L2): give each label one contiguous
-    // eighth of the envs. Bijective for any grid size; a speed choice only.
-    const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
-#else
-    return blockIdx.x;
+    if (order & 1u) {
+        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        c = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
 #endif
+    if ((order & 2u) && (gstep & 1u)) c = gridDim.x - 1u - c;
+    return c;
 }
 
 #if DRONE_STEP_MIN_WAVES > 0
@@ -425,7 +429,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     float4* const tile = sh.obs_tile[threadIdx.x / kWave];
     // This workgroup walks DRONE_STEP_TILES consecutive 256-drone chunks. Lanes [n, n_pad) exist in the planes
     // and hold a valid reset state: they load and compute like the rest and store nothing.
-    uint32_t block_base = my_chunk() * (uint32_t)(DRONE_STEP_TILES * kBlock);
+    uint32_t block_base = my_chunk(a.v.order, a.gstep) * (uint32_t)(DRONE_STEP_TILES * kBlock);
 #if DRONE_STAMPS
     unsigned long long stamp_[kStampSlots];
     stamp_[8] = __builtin_amdgcn_s_memrealtime();
@@ -571,7 +575,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
-    const uint32_t block_base = my_chunk() * kBlock;
+    const uint32_t block_base = my_chunk(a.v.order & 1u, 0u) * kBlock;
     const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
     Lane L;

@@ -8,7 +8,7 @@
  * here: both stay behind the C-ABI.
  *
  *   drone_host_mp [--gpus G] [--envs TOTAL] [--steps K] [--task 0..3] [--seed S]
- *                 [--gather 0|1] [--rollout T] [--crc 1]
+ *                 [--gather 0|1] [--rollout T] [--crc 1] [--share-devices 1]
  *
  * Rank r takes envs [offset_r, offset_r + count_r) (the first TOTAL % G ranks get
  * one more) on device r. The RCCL unique id is made by rank 0 AFTER the fork and
@@ -18,6 +18,9 @@
  * Rank 0 prints one JSON line; with --crc 1 the CRC-32 chained over every step's
  * gathered batch, which tests/test_c_host.py compares with the CPU oracle's.
  * --rollout T: fused T-step rollouts with the gather once per horizon (configs[4]).
+ * --share-devices 1: rank r uses device r %% (visible devices) — lets the fork / shard / barrier logic run with several
+ *   ranks on a one-GPU box (without --gather: RCCL refuses two ranks on one device); every rank's CRC over ITS OWN
+ *   slice is printed so a test can check each shard against the oracle.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -37,6 +40,7 @@ typedef struct Shared {
     volatile int arrived[2]; /* sense-reversing barrier over the ranks */
     volatile int sense;
     double rank_seconds[64];
+    uint32_t rank_crc[64]; /* CRC-32 of each rank's own slice of the outputs, chained over the launches */
 } Shared;
 
 static uint32_t crc32_update(uint32_t crc, const void* buf, size_t len) {
@@ -75,7 +79,7 @@ static void barrier(Shared* sh, int world, int* local_sense) {
 }
 
 typedef struct Opts {
-    int gpus, total, steps, task, gather, rollout, crc;
+    int gpus, total, steps, task, gather, rollout, crc, share;
     unsigned long long seed;
 } Opts;
 
@@ -102,6 +106,11 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     drone_config_default(&cfg, o->task);
     cfg.buffer_kind = DRONE_BUFFERS_HOST;
     cfg.device = rank; /* one process per GPU */
+    if (o->share) {
+        const int ndev = drone_device_count();
+        if (ndev < 1) { fprintf(stderr, "rank %d: no HIP device\n", rank); return 1; }
+        cfg.device = rank % ndev;
+    }
     cfg.env_offset = (uint32_t)offsets[rank];
     DroneVec* v = drone_vec_init(all_obs + (size_t)offsets[rank] * od, act, all_rew + offsets[rank], all_term + offsets[rank],
                                  all_trunc + offsets[rank], n, o->seed, &cfg);
@@ -127,8 +136,12 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     int sense = 0;
     drone_vec_reset(v, o->seed);
     if (o->gather && drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
-    uint32_t crc = 0;
-    if (o->crc) crc = crc32_update(crc, all_obs, sizeof(float) * total * od);
+    uint32_t crc = 0, own = 0;
+    const size_t off = (size_t)offsets[rank];
+    if (o->crc) {
+        crc = crc32_update(crc, all_obs, sizeof(float) * total * od);
+        own = crc32_update(own, all_obs + off * od, sizeof(float) * (size_t)n * od);
+    }
     const int launches = o->rollout > 0 ? (o->steps + o->rollout - 1) / o->rollout : o->steps;
     barrier(sh, world, &sense);
     const double t0 = now_s();
@@ -145,8 +158,13 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
             crc = crc32_update(crc, all_rew, sizeof(float) * total);
             crc = crc32_update(crc, all_term, total);
             crc = crc32_update(crc, all_trunc, total);
+            own = crc32_update(own, all_obs + off * od, sizeof(float) * (size_t)n * od);
+            own = crc32_update(own, all_rew + off, sizeof(float) * (size_t)n);
+            own = crc32_update(own, all_term + off, (size_t)n);
+            own = crc32_update(own, all_trunc + off, (size_t)n);
         }
     }
+    sh->rank_crc[rank] = own;
     sh->rank_seconds[rank] = now_s() - t0;
     if (drone_vec_status(v)) { fprintf(stderr, "rank %d: %s\n", rank, drone_vec_status_message(v)); return 1; }
     barrier(sh, world, &sense);
@@ -155,9 +173,11 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
         for (int r = 0; r < world; r++) el = sh->rank_seconds[r] > el ? sh->rank_seconds[r] : el;
         const double env_steps = (double)o->total * (o->rollout > 0 ? (double)o->rollout : 1.0) * launches;
         printf("{\"mode\": \"%s%s\", \"gpus\": %d, \"task\": %d, \"envs\": %d, \"launches\": %d, \"horizon\": %d, \"env_steps_per_s\": %.4g, "
-               "\"ms_per_launch\": %.4f, \"crc32\": %u}\n",
+               "\"ms_per_launch\": %.4f, \"crc32\": %u, \"rank_crc32\": [",
                o->rollout > 0 ? "fused rollout" : "per-step", o->gather ? " + RCCL all-gather to every rank's host batch" : " (no gather)", world, o->task,
                o->total, launches, o->rollout, env_steps / el, el * 1e3 / launches, crc);
+        for (int r = 0; r < world; r++) printf("%s%u", r ? ", " : "", sh->rank_crc[r]);
+        printf("]}\n");
         fflush(stdout);
     }
     if (o->gather) drone_vec_gather_close(v);
@@ -167,7 +187,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
 }
 
 int main(int argc, char** argv) {
-    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0ull};
+    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 0ull};
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--gpus")) o.gpus = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--envs")) o.total = atoi(argv[i + 1]);
@@ -176,6 +196,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--gather")) o.gather = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--rollout")) o.rollout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--crc")) o.crc = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--share-devices")) o.share = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) o.seed = strtoull(argv[i + 1], NULL, 10);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }

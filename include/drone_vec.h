@@ -88,6 +88,9 @@ typedef struct DroneVec DroneVec;
 
 void drone_config_default(DroneConfig* cfg, int task);
 
+/* HIP devices visible to this process (0 if none / HIP unusable); a multi-process host maps ranks onto them. */
+int drone_device_count(void);
+
 /* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM and DRONE_TASK_RACE. */
 int drone_obs_dim(int task);
 

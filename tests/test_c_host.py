@@ -96,3 +96,31 @@ def test_c_host_mp_gather_matches_oracle(exe, oracle, task, rollout):
     want, _ = oracle_crc(oracle, task, envs, steps, seed, rollout=rollout)
     assert got["crc32"] == want, f"task {task}: gathered crc {got['crc32']:#x} != oracle {want:#x}"
     assert got["env_steps_per_s"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,envs", [(2, 6000), (3, 10001)])
+def test_c_host_mp_forks_shards_on_one_gpu(exe, oracle, ranks, envs):
+    """Several ranks forked before HIP, sharing the one GPU (no gather: RCCL refuses two ranks on a device): every
+    rank's own slice, CRC'd over all launches, equals the oracle run of that shard — ragged split, global env ids."""
+    steps, seed, task = 64, 23, 1
+    cmd = [EXE_MP, "--gpus", str(ranks), "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed),
+           "--crc", "1", "--gather", "0", "--share-devices", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert got["gpus"] == ranks and len(got["rank_crc32"]) == ranks
+    off = 0
+    for rank in range(ranks):
+        cnt = envs // ranks + (1 if rank < envs % ranks else 0)
+        o = oracle.OracleVec(cnt, seed=seed, cfg=oracle.default_config(task, env_offset=off), threads=4)
+        o.reset(seed)
+        crc = zlib.crc32(o.observations.tobytes())
+        for _ in range(steps):
+            o.fill_random_actions()
+            o.step()
+            for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+                crc = zlib.crc32(buf.tobytes(), crc)
+        o.close()
+        assert got["rank_crc32"][rank] == crc, f"rank {rank} (envs {off}..{off + cnt})"
+        off += cnt

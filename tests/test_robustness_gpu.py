@@ -202,3 +202,27 @@ def test_c_abi_gather_host_buffers_ragged_counts(oracle, hip, monkeypatch):
         assert_bits_equal(o.truncations, g_trunc, f"trunc {t}")
     assert_outputs_equal(o, h, "local buffers still filled")
     h.gather_close()
+
+
+@pytest.mark.parametrize("order", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("n", [5000, 70001])
+def test_sweep_orders_are_bijective(oracle, hip, monkeypatch, order, n):
+    """DRONE_SWEEP_ORDER only permutes which workgroup takes which 256-drone chunk (round-robin / one eighth per XCD,
+    forward / reversed on odd steps): every order must give the oracle's results, odd grid sizes included. The
+    line-complete widening of episode-end writes is forced on as well (small shards normally leave it off)."""
+    monkeypatch.setenv("DRONE_SWEEP_ORDER", order)
+    monkeypatch.setenv("DRONE_LINE_COMPLETE", "1")
+    o, h = make_pair(oracle, hip, n, 41, 1, device="cuda:0", horizon=9, compact_done=1)
+    for t in range(40):
+        o.fill_random_actions()
+        h.fill_random_actions()
+        o.step()
+        h.step()
+        if t % 9 == 8:
+            want = np.flatnonzero(o.terminals | o.truncations).astype(np.uint32)
+            assert_bits_equal(want, np.sort(h.done_list()), f"done ids step {t}")
+    assert_outputs_equal(o, h, f"order {order}")
+    assert_state_equal(o.get_state(), h.get_state(), f"order {order} state")
+    o.rollout(17)
+    h.rollout(17)
+    assert_state_equal(o.get_state(), h.get_state(), f"order {order} state after rollout")
