@@ -53,6 +53,7 @@ class BoundaryGather:
         self.equal = len(set(self.counts)) == 1
         self.max_count = max(self.counts)
         rows = self.total if self.equal else self.max_count * self.world
+        self._coalesce = True  # falls back to four plain collectives the first time the grouped launch is refused
         self.obs = torch.empty((rows, obs_dim), dtype=torch.float32, device=device)
         self.rew = torch.empty(rows, dtype=torch.float32, device=device)
         self.term = torch.empty(rows, dtype=torch.uint8, device=device)
@@ -71,17 +72,26 @@ class BoundaryGather:
         """Gather this rank's outputs; returns global (obs, rew, term, trunc) in env-id order."""
         srcs = {"obs": obs, "rew": rew, "term": term, "trunc": trunc}
         dsts = {"obs": self.obs, "rew": self.rew, "term": self.term, "trunc": self.trunc}
-        if self.equal:
-            with _one_launch(self.group, self.obs.device):
-                for k in srcs:
-                    dist.all_gather_into_tensor(dsts[k], srcs[k].contiguous(), group=self.group)
-            return self.obs, self.rew, self.term, self.trunc
-        mine = self.counts[self.rank]
-        for k in srcs:
-            self._pad[k][:mine].copy_(srcs[k])
-        with _one_launch(self.group, self.obs.device):
+        if not self.equal:
+            mine = self.counts[self.rank]
             for k in srcs:
-                dist.all_gather_into_tensor(dsts[k], self._pad[k], group=self.group)
+                self._pad[k][:mine].copy_(srcs[k])
+            srcs = self._pad
+        else:
+            srcs = {k: t.contiguous() for k, t in srcs.items()}
+        if self._coalesce:
+            try:
+                with _one_launch(self.group, self.obs.device):
+                    for k in srcs:
+                        dist.all_gather_into_tensor(dsts[k], srcs[k], group=self.group)
+            except (RuntimeError, TypeError, ValueError):
+                # raised at enqueue time on every rank alike (an unsupported grouping), before anything was launched
+                self._coalesce = False
+        if not self._coalesce:
+            for k in srcs:
+                dist.all_gather_into_tensor(dsts[k], srcs[k], group=self.group)
+        if self.equal:
+            return self.obs, self.rew, self.term, self.trunc
         keep = self._keep
         return self.obs[keep], self.rew[keep], self.term[keep], self.trunc[keep]
 
