@@ -159,8 +159,33 @@ def reset_draws(c, seed, env, episode, task):
     return out
 
 
+def neighbour(c, pos):
+    """SPEC.md §10: nearest neighbour of every agent among the A consecutive agents of its swarm, scanning
+    d = 1 .. A-1 places round the swarm and keeping the first strict minimum. Returns (d2, e, gap) with `gap` the
+    distance in d2 to the runner-up (a near-tie may be decided differently in float32)."""
+    A = int(c["agents_per_env"])
+    n = len(pos)
+    P = pos.reshape(n // A, A, 3)
+    best = np.full((n // A, A), (4.0 * c["bound"]) ** 2)
+    second = np.full((n // A, A), np.inf)
+    e_best = np.zeros((n // A, A, 3))
+    for d in range(1, A):
+        e = np.roll(P, -d, axis=1) - P          # p_{(i+d) mod A} - p_i
+        d2 = (e * e).sum(-1)
+        take = d2 < best
+        second = np.where(take, best, np.minimum(second, d2))
+        e_best = np.where(take[..., None], e, e_best)
+        best = np.where(take, d2, best)
+    return best.reshape(n), e_best.reshape(n, 3), (second - best).reshape(n)
+
+
 def full_obs(c, S, target, aux, task):
     o = obs(c, S, target)
+    if task == 2:
+        p, v, q, om, r = S
+        d2, e, _ = neighbour(c, p)
+        eb = np.einsum("nij,ni->nj", rot(q), e) * (0.5 / c["bound"])
+        o = np.concatenate([o, eb, (d2 / c["bound"] ** 2)[:, None]], 1)
     if task == 3:
         p, v, q, om, r = S
         R = rot(q)
@@ -202,10 +227,17 @@ def env_step(c, seed, task, st, actions, gstep, env_ids):
     score = st["score_count"].copy()
     aux = wind.copy() if task == 1 else st["wind"].copy()
     episode = st["episode"].copy()
-    if task == 0:
+    if task in (0, 2):
         rew = 1.0 - dist * (0.5 / c["bound"]) - pen
         score = score + (dist < c["hover_radius"])
         margin = np.minimum(margin, np.abs(dist - c["hover_radius"]))
+        if task == 2:  # §10: collisions and the proximity penalty, on the post-integration positions of every agent
+            nn_d2, _, gap = neighbour(c, p)
+            coll_r2 = c["collision_radius"] ** 2
+            oob = oob | (nn_d2 < coll_r2)
+            trunc = ~oob & (tick >= c["horizon"])
+            margin = np.minimum(margin, np.abs(nn_d2 - coll_r2))
+            rew = rew - c["c_proximity"] * np.maximum(0.0, 1.0 - nn_d2 / c["proximity_radius"] ** 2)
     elif task == 1:
         rew = c["progress_scale"] * (prev_dist - dist) - pen
         hit = ~oob & (dist < c["waypoint_radius"])
@@ -240,7 +272,7 @@ def env_step(c, seed, task, st, actions, gstep, env_ids):
     ep_return = st["ep_return"] + rew
     done = oob | trunc
     logs = {k: st[k].copy() for k in ("perf_sum", "score_sum", "ret_sum", "len_sum", "n_sum", "oob_sum")}
-    if task == 0:
+    if task in (0, 2):
         sc = score / np.maximum(tick, 1)
         perf = sc
     else:
@@ -263,4 +295,12 @@ def env_step(c, seed, task, st, actions, gstep, env_ids):
     new["episode"] = episode
     new.update(logs)
     S2 = [new[k] for k in ("pos", "vel", "quat", "omega", "rpm")]
+    if task == 2:
+        # an agent's reset moves its neighbours' observation too; a near-tie between two neighbours, before or after
+        # the resets, may pick the other one in float32: such swarms are excluded through the margin
+        A = int(c["agents_per_env"])
+        _, _, gap_after = neighbour(c, new["pos"])
+        tie = np.minimum(gap, gap_after)
+        margin = np.minimum(margin, tie)
+        margin = np.repeat(margin.reshape(-1, A).min(1), A)  # one borderline agent makes its whole swarm borderline
     return new, (rew, oob, trunc), full_obs(c, S2, new["target"], new["wind"], task), margin
