@@ -16,7 +16,7 @@ struct DeviceView {
     uint32_t n;          // envs on this device
     uint32_t n_pad;      // n rounded up to a whole workgroup: lanes [n, n_pad) exist and hold a valid reset state
     uint32_t stride;     // float4 elements between the two cold planes (>= n_pad)
-    uint32_t order;      // sweep order of the step kernel's workgroups: bit 0 one contiguous eighth per XCD, bit 1 reverse on odd steps (drone_kernels.hip my_chunk)
+    uint32_t order;      // sweep order of the step kernel's workgroups: bit 0 one contiguous eighth per XCD, bit 1 reverse on odd steps, bit 2 non-temporal action loads (drone_kernels.hip my_chunk)
     uint32_t line_complete; // 1: rare per-lane plane updates go out as whole 128-B lines (working set beyond the Infinity Cache)
     const uint32_t* kp;  // KParams in HBM (kParamWords words) — read only by the LDS-staging build
     const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)

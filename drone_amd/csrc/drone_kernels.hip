@@ -39,6 +39,9 @@
 #ifndef DRONE_NT_STATE_STORES  // 1: non-temporal stores for the state planes too (0 … -7 % by shard size, never slower)
 #define DRONE_NT_STATE_STORES 1
 #endif
+#ifndef DRONE_NT_ACTION_LOADS  // 1: the action rows (read once per step, never again by this path) are loaded non-temporally
+#define DRONE_NT_ACTION_LOADS 0
+#endif
 #ifndef DRONE_XCD_REMAP  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the envs (-3 % step)
 #define DRONE_XCD_REMAP 1
 #endif
@@ -169,7 +172,7 @@ struct RawLane {
 // No branches in here: the wait-count pass merges the outstanding-load state of all paths into a join and would
 // make the consumer of the CURRENT chunk wait for the prefetched one too. `ia` is the action row to read, already
 // clamped into the buffer by the caller (lanes >= n read the last row and never store anything).
-template <int TASK>
+template <int TASK, bool STREAM>
 __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawLane<TASK>& R) {
     R.a = pl[hot_index(hot_planes(TASK), kP0, i, np)];
     R.b = pl[hot_index(hot_planes(TASK), kP1, i, np)];
@@ -178,7 +181,14 @@ __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const fl
     R.e = pl[hot_index(hot_planes(TASK), kP4, i, np)];
     R.t = pl[hot_index(hot_planes(TASK), kPT, i, np)];
     if (has_aux_plane<TASK>()) R.w = pl[hot_index(hot_planes(TASK), kPW, i, np)];
-    R.act = reinterpret_cast<const float4*>(actions)[ia];
+    // Non-temporal only where nothing is cached anyway (STREAM: the host picks that instantiation by footprint: -2 % at
+    // 2^22 envs, but +19 % at 2^20 and +7 % at 131 072, where the hint pushes the rows out of the caches that serve them).
+    if (STREAM) {  // compile time: a run-time branch here would make the wait-count pass drain all loads at the join
+        const f4_t av = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(actions) + ia);
+        R.act = make_float4(av.x, av.y, av.z, av.w);
+    } else {
+        R.act = reinterpret_cast<const float4*>(actions)[ia];
+    }
 }
 
 template <int TASK>
@@ -391,7 +401,8 @@ __device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float4*
 
 // which 256-drone chunk this workgroup owns. `order` (a launch argument, chosen by the host from the step's
 // footprint; DeviceView::order) — bit 0: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the
-// envs instead of being dealt round-robin over one global sweep; bit 1 (odd steps only): sweep in reverse, so the
+// envs instead of being dealt round-robin over one global sweep; bit 2: non-temporal action loads (load_raw);
+// bit 1 (odd steps only): sweep in reverse, so the
 // lines touched last in one step are the first touched in the next and are still in the Infinity Cache.
 // Bijective for any grid size; a speed choice only (profiles/r02_ab/ab_zz_*.txt, ab_order_*.txt).
 __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep) {
@@ -420,7 +431,7 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep) {
 // =====================================================================
 // per-step kernel (SPEC.md §5): configs 1–4
 // =====================================================================
-template <int TASK, bool COMPACT>
+template <int TASK, bool COMPACT, bool STREAM = false>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -436,7 +447,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
 #endif
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
-    load_raw<TASK>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
+    load_raw<TASK, STREAM>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[a.done_slot ^ 1u] = 0u;  // arm the next step launch's counter
 #pragma unroll
     for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
@@ -446,7 +457,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         const bool more = t + 1 < DRONE_STEP_TILES && block_base + kBlock < n_pad;  // workgroup-uniform
         if (t + 1 < DRONE_STEP_TILES) {  // compile-time: the next chunk's loads are in flight while this one computes
             const uint32_t j = min(i + kBlock, n_pad - kBlock + threadIdx.x);  // past the end: this chunk again (unused)
-            load_raw<TASK>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
+            load_raw<TASK, STREAM>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
         }
 
         Lane L;
@@ -686,19 +697,17 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     a.done_slot = done_slot & 1u;
     const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
     const bool compact = v.done_ids != nullptr;
-    if (task == DRONE_TASK_HOVER) {
-        if (compact) drone_step_kernel<DRONE_TASK_HOVER, true><<<g, b, 0, s>>>(a);
-        else drone_step_kernel<DRONE_TASK_HOVER, false><<<g, b, 0, s>>>(a);
-    } else if (task == DRONE_TASK_SWARM) {
-        if (compact) drone_step_kernel<DRONE_TASK_SWARM, true><<<g, b, 0, s>>>(a);
-        else drone_step_kernel<DRONE_TASK_SWARM, false><<<g, b, 0, s>>>(a);
-    } else if (task == DRONE_TASK_RACE) {
-        if (compact) drone_step_kernel<DRONE_TASK_RACE, true><<<g, b, 0, s>>>(a);
-        else drone_step_kernel<DRONE_TASK_RACE, false><<<g, b, 0, s>>>(a);
-    } else {
-        if (compact) drone_step_kernel<DRONE_TASK_WAYPOINT, true><<<g, b, 0, s>>>(a);
-        else drone_step_kernel<DRONE_TASK_WAYPOINT, false><<<g, b, 0, s>>>(a);
-    }
+    const bool stream = (v.order & 4u) != 0 || DRONE_NT_ACTION_LOADS;  // non-temporal action loads: HBM-only footprints
+#define DRONE_LAUNCH_STEP(T)                                                                 \
+    do {                                                                                     \
+        if (compact) { if (stream) drone_step_kernel<T, true, true><<<g, b, 0, s>>>(a); else drone_step_kernel<T, true, false><<<g, b, 0, s>>>(a); } \
+        else { if (stream) drone_step_kernel<T, false, true><<<g, b, 0, s>>>(a); else drone_step_kernel<T, false, false><<<g, b, 0, s>>>(a); }    \
+    } while (0)
+    if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_STEP(DRONE_TASK_HOVER);
+    else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_STEP(DRONE_TASK_SWARM);
+    else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_STEP(DRONE_TASK_RACE);
+    else DRONE_LAUNCH_STEP(DRONE_TASK_WAYPOINT);
+#undef DRONE_LAUNCH_STEP
     return hipGetLastError();
 }
 

@@ -488,12 +488,12 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         const char* e = getenv("DRONE_LINE_COMPLETE");
         const size_t touched = n * (sizeof(float4) * (2 * hot_planes(cfg->task) - 1) + (size_t)drone_obs_dim(cfg->task) * 4 + 16 + 6);
         v->dv.line_complete = (e && *e) ? (atoi(e) != 0) : (touched > ((size_t)512 << 20));
-        // Sweep order of the step kernel, by the same footprint (DRONE_SWEEP_ORDER=0..3 forces it): up to ~1.5x the
+        // Sweep order of the step kernel, by the same footprint (DRONE_SWEEP_ORDER=0..7 forces it): up to ~1.5x the
         // Infinity Cache, one contiguous eighth per XCD (-2.7 % at 2^20 envs); beyond, one global round-robin sweep
         // (-6 % at 2^21) that turns around on odd steps once a step dwarfs the cache (-6 % at 2^22: the tail of one
-        // step is the head of the next and is still cached).
+        // step is the head of the next and is still cached), with the action rows streamed (bit 2: -2 % there).
         const char* o = getenv("DRONE_SWEEP_ORDER");
-        v->dv.order = (o && *o) ? (uint32_t)atoi(o) : (touched <= ((size_t)400 << 20) ? 1u : touched <= ((size_t)768 << 20) ? 0u : 2u);
+        v->dv.order = (o && *o) ? (uint32_t)atoi(o) : (touched <= ((size_t)400 << 20) ? 1u : touched <= ((size_t)768 << 20) ? 0u : 6u);
     }
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
