@@ -105,6 +105,13 @@ namespace {
 // torch with another current device, must not find its device changed by a
 // step()); a failure anywhere inside the call sticks to the handle
 // (drone_vec_status) because the path calls themselves return void.
+// puts the caller's current device back when the scope ends (init, which has no handle yet)
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct Entry {
     DroneVec* v;
     int prev = -1;
@@ -407,6 +414,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device), return nullptr);
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { set_err("device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName); return nullptr; }
 
+    DeviceRestore restore_callers_device;
     DroneVec* v = new (std::nothrow) DroneVec();
     if (!v) { set_err("out of memory"); return nullptr; }
     memset(v, 0, sizeof(*v));
