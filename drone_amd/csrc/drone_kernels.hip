@@ -1,20 +1,29 @@
 // drone_kernels.hip — gfx950 (CDNA4, MI355X) kernels of the drone env.
 //
-// One lane = one drone. State lives in HBM as float4 planes (drone_params.hpp),
-// so every state access is a 16-B-per-lane, 1-KiB-per-wave coalesced
-// global_load/store_dwordx4. Outputs leave in whole cache lines and
-// non-temporally (nothing on the GPU re-reads them in this path):
+// One lane = one drone. The state a step always touches lives in HBM as float4
+// planes interleaved per 64-drone wave tile (drone_params.hpp), so a wave
+// streams ONE contiguous 6-7 KiB piece with global_load/store_dwordx4 (16 B per
+// lane, one base address + immediate offsets). Outputs leave in whole cache
+// lines and non-temporally (nothing on the GPU re-reads them in this path):
 //   * observation rows ([N][20] AoS, what a vec-env consumer expects) are
-//     transposed through a wave-private LDS tile, so a wave emits five 1-KiB
-//     stores instead of 64 strided 80-B rows (2.5x on the whole kernel);
+//     transposed through a wave-private LDS tile (wave-scope fences only, no
+//     workgroup barrier), so a wave emits five 1-KiB stores instead of 64
+//     strided 80-B rows (2.5x on the whole kernel);
 //   * terminal / truncation bytes are built from the waves' __ballot masks,
 //     gathered per workgroup in LDS and written as 16-B pieces by the first 32
 //     lanes — partial-line dword stores of the same bytes cost 11 % of the kernel;
 //   * the optional done-id list is compacted with ballot + mbcnt + one atomic
-//     per wave.
-// The 52-word constants block (KParams) reaches the lanes either through the
-// kernarg segment (scalar loads -> SGPR operands; default, measured faster) or
-// staged through LDS by each workgroup (DRONE_PARAMS_IN_LDS=1).
+//     per wave;
+//   * the rare per-lane plane updates of an ended episode are widened to whole
+//     128-B lines when the footprint exceeds the Infinity Cache (whole_lines).
+// vmcnt retires in issue order, stores included, and the wait-count pass merges
+// both paths' outstanding counts at a join: hence no branch around the loads or
+// the state stores, the log-plane loads ahead of the stores, their fold last.
+// The sweep order over the envs, the line widening and the action-load hint are
+// launch arguments chosen by the host from the step's footprint (DeviceView).
+// The 57-word constants block (KParams) reaches the lanes through the kernarg
+// segment (scalar loads -> SGPR operands; default), staged through LDS by each
+// workgroup (DRONE_PARAMS_IN_LDS=1) or by scalar loads from HBM (DRONE_PARAMS_GLOBAL=1).
 //
 // The path is elementwise: no MFMA. Roofline = HBM for the per-step kernel,
 // f32 VALU for the fused rollout.
@@ -26,23 +35,23 @@
 #include "drone_lane.hpp"
 
 // ---- tuning knobs (compile-time). Defaults are the measured best at equal
-// memory placement: DESIGN.md "Tuning log", profiles/r01_ab_*.txt ----
-#ifndef DRONE_PARAMS_GLOBAL  // 1: KParams read by scalar loads from the handle's HBM copy (constant address space) instead of by value in the kernarg segment: a 228-B shorter kernarg fetch ahead of the first state load
+// memory placement (tools/ab_step.py): DESIGN.md, profiles/r01_ab/, profiles/r02_ab/ ----
+#ifndef DRONE_PARAMS_GLOBAL  // 1: KParams read by scalar loads from the handle's HBM copy (constant address space) instead of by value in the kernarg segment: a 228-B shorter kernarg fetch ahead of the first state load (no measurable effect, ab_pg_*)
 #define DRONE_PARAMS_GLOBAL 0
 #endif
 #ifndef DRONE_PARAMS_IN_LDS  // 1: stage KParams HBM -> LDS per workgroup; 0: kernarg scalar loads (-2.4 % step, -13 % rollout)
 #define DRONE_PARAMS_IN_LDS 0
 #endif
-#ifndef DRONE_NT_STORES  // 1: non-temporal stores for observations / rewards / flags (-5 % step)
+#ifndef DRONE_NT_STORES  // 1: non-temporal stores for observations / rewards / flags (plain stores: +21 % at 2^20 envs, +11 % at 131 072, 0 at 2^22; ab_nt_*)
 #define DRONE_NT_STORES 1
 #endif
-#ifndef DRONE_NT_STATE_STORES  // 1: non-temporal stores for the state planes too (0 … -7 % by shard size, never slower)
+#ifndef DRONE_NT_STATE_STORES  // 1: non-temporal stores for the state planes too (plain: +0.4 % at 2^20, +4 % at 131 072, 0 at 2^22)
 #define DRONE_NT_STATE_STORES 1
 #endif
-#ifndef DRONE_NT_ACTION_LOADS  // 1: the action rows (read once per step, never again by this path) are loaded non-temporally
+#ifndef DRONE_NT_ACTION_LOADS  // 1: force non-temporal action loads at every size (default: only the instantiation the host picks for HBM-only footprints)
 #define DRONE_NT_ACTION_LOADS 0
 #endif
-#ifndef DRONE_XCD_REMAP  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the envs (-3 % step)
+#ifndef DRONE_XCD_REMAP  // 0: compile the per-XCD chunk map out (it is otherwise a launch-time choice: DeviceView::order bit 0)
 #define DRONE_XCD_REMAP 1
 #endif
 #ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset. 5 keeps the race task at 93 VGPRs (97 unbounded), no scratch
@@ -52,7 +61,7 @@
 #define DRONE_STEP_MAX_WAVES 0
 #endif
 
-#ifndef DRONE_STEP_TILES  // 256-drone chunks per workgroup of the per-step kernel, software-pipelined: the loads of chunk k+1 are in flight while chunk k computes
+#ifndef DRONE_STEP_TILES  // 256-drone chunks per workgroup of the per-step kernel, software-pipelined: the loads of chunk k+1 are in flight while chunk k computes. Measured SLOWER (+13 % at 2^20 with 2, ab_tiles_*): kept as the negative result
 #define DRONE_STEP_TILES 1
 #endif
 
