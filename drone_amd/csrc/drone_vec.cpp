@@ -271,10 +271,13 @@ Rccl* rccl() {
     if (r.lib) return &r;
     if (tried) { set_err("librccl could not be loaded earlier in this process"); return nullptr; }
     tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // DRONE_RCCL_LIB: another library with the same eight entry points (tests/rccl_stub: lets several ranks share one
+    // GPU, which RCCL itself refuses)
+    const char* alt = getenv("DRONE_RCCL_LIB");
+    const char* names[] = {alt && *alt ? alt : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib) break;
+        if (r.lib || (alt && *alt)) break;  // an explicit choice is not silently replaced
     }
     if (!r.lib) { set_err("dlopen(librccl.so.1) failed: %s", dlerror()); return nullptr; }
 #define RCCL_SYM(field, name)                                                        \
@@ -320,6 +323,7 @@ struct Gather {
     float* h_rew = nullptr;
     unsigned char* h_term = nullptr;
     unsigned char* h_trunc = nullptr;
+    bool h_registered[4] = {false, false, false, false};  // the global host buffers pinned by gather_init
 };
 
 namespace {
@@ -331,6 +335,9 @@ void gather_destroy(DroneVec* v) {
         Rccl* R = rccl();
         if (R) (void)R->CommDestroy(g->comm);
     }
+    void* hosts[4] = {g->h_obs, g->h_rew, g->h_term, g->h_trunc};
+    for (int k = 0; k < 4; k++)
+        if (g->h_registered[k]) (void)hipHostUnregister(hosts[k]);
     if (g->own_staging) {
         (void)hipFree(g->g_obs);
         (void)hipFree(g->g_rew);
@@ -874,6 +881,17 @@ int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int wo
         if (v->zero_copy) leave_zero_copy(v);
         g->own_staging = true;
         g->h_obs = all_observations; g->h_rew = all_rewards; g->h_term = all_terminals; g->h_trunc = all_truncations;
+        // The local output buffers were pinned at init. Where they are slices of the global ones (the usual layout), a
+        // copy into the whole global buffer would then span pinned and pageable pages, which HIP rejects: drop the
+        // local pins (the mirror transport does not need them) and pin the global buffers whole instead, best effort.
+        for (int slot : {0, 2, 3, 4})
+            if (v->registered[slot]) { (void)hipHostUnregister(v->registered_ptr[slot]); v->registered[slot] = false; }
+        void* hosts[4] = {all_observations, all_rewards, all_terminals, all_truncations};
+        const size_t bytes[4] = {g->total * od * sizeof(float), g->total * sizeof(float), g->total, g->total};
+        for (int k = 0; k < 4; k++) {
+            g->h_registered[k] = hipHostRegister(hosts[k], bytes[k], hipHostRegisterDefault) == hipSuccess;
+            if (!g->h_registered[k]) (void)hipGetLastError();
+        }
 #define G_TRY(expr) HIP_TRY(expr, { gather_destroy(v); return -1; })
         G_TRY(hipMalloc((void**)&g->g_obs, g->total * od * sizeof(float)));
         G_TRY(hipMalloc((void**)&g->g_rew, g->total * sizeof(float)));

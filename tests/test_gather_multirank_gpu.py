@@ -1,0 +1,114 @@
+"""The rank > 0 side of the C-ABI gather on a ONE-GPU box. RCCL refuses two ranks on one device, so these tests load
+tests/rccl_stub (a shared-memory test double with RCCL's documented semantics, selected with DRONE_RCCL_LIB) and run
+2 and 3 ranks that share the GPU: slice offsets, ragged counts (the all-gather-v branch), in-place device buffers,
+host staging. What stays untested without a multi-GPU box is RCCL itself, not this library's use of it."""
+import json
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE_MP = os.path.join(ROOT, "host", "drone_host_mp")
+
+
+@pytest.fixture(scope="module")
+def stub(tmp_path_factory, hip):
+    out = str(tmp_path_factory.mktemp("stub") / "librccl_stub.so")
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tests", "rccl_stub", "rccl_stub.c"),
+                    "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib", "-o", out], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "host"), "-B"], check=True, capture_output=True)
+    return out
+
+
+@pytest.mark.parametrize("ranks,envs,task,rollout", [(2, 6000, 0, 0), (3, 10001, 1, 0), (2, 4096, 3, 16), (3, 6144, 2, 0)])
+def test_c_host_mp_gathers_across_ranks(stub, oracle, ranks, envs, task, rollout):
+    """host/drone_host_mp with several ranks: fork before HIP, id through the shared page, gather_init with the ranks'
+    counts (equal -> all-gather, ragged -> one broadcast per rank), the gathered batch of every launch CRC'd on rank 0
+    against ONE oracle run over all envs — so every rank's slice landed at its global offset."""
+    steps, seed = 48, 31
+    cmd = [EXE_MP, "--gpus", str(ranks), "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed),
+           "--crc", "1", "--gather", "1", "--share-devices", "1"]
+    if rollout:
+        cmd += ["--rollout", str(rollout)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, DRONE_RCCL_LIB=stub))
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=4)
+    o.reset(seed)
+    crc = zlib.crc32(o.observations.tobytes())
+    launches = steps if not rollout else (steps + rollout - 1) // rollout
+    for _ in range(launches):
+        if rollout:
+            o.rollout(rollout)
+        else:
+            o.fill_random_actions()
+            o.step()
+        for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+            crc = zlib.crc32(buf.tobytes(), crc)
+    assert got["crc32"] == crc, f"{ranks} ranks: gathered crc {got['crc32']:#x} != oracle {crc:#x}"
+
+
+_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from drone_amd import abi, binding
+from drone_amd.dist import shard_range
+rank, world, total, task, steps, seed = (int(x) for x in sys.argv[1:7])
+idfile = sys.argv[7]
+dev = torch.device("cuda:0")
+off, cnt = shard_range(total, rank, world)
+od = abi.obs_dim(task)
+g_obs = torch.zeros((total, od), dtype=torch.float32, device=dev); g_rew = torch.zeros(total, dtype=torch.float32, device=dev)
+g_term = torch.zeros(total, dtype=torch.uint8, device=dev); g_trunc = torch.zeros(total, dtype=torch.uint8, device=dev)
+act = torch.zeros((cnt, 4), dtype=torch.float32, device=dev)
+sl = slice(off, off + cnt)
+v = binding.DroneVec(cnt, seed=seed, cfg=binding.default_config(task, env_offset=off, horizon=20), buffers=(g_obs[sl], act, g_rew[sl], g_term[sl], g_trunc[sl]))
+if rank == 0:
+    uid = binding.gather_unique_id()
+    with open(idfile + ".tmp", "wb") as fh: fh.write(uid)
+    os.rename(idfile + ".tmp", idfile)
+else:
+    import time
+    while not os.path.exists(idfile): time.sleep(0.01)
+    uid = open(idfile, "rb").read()
+v.gather_init(uid, rank, world, g_obs, g_rew, g_term, g_trunc, counts=[shard_range(total, r, world)[1] for r in range(world)])
+v.reset(seed); v.gather()
+for t in range(steps):
+    v.fill_random_actions(); v.step(); v.gather()
+torch.cuda.synchronize()
+np.savez(sys.argv[8], obs=g_obs.cpu().numpy(), rew=g_rew.cpu().numpy(), term=g_term.cpu().numpy(), trunc=g_trunc.cpu().numpy())
+v.gather_close(); v.close()
+"""
+
+
+@pytest.mark.parametrize("world,total,task", [(2, 8192, 0), (3, 7001, 1)])
+def test_in_place_device_gather_across_ranks(stub, oracle, tmp_path, world, total, task):
+    """Device buffers: every rank's output buffers ARE its slice of its global buffers (the in-place form bench.py's
+    C-ABI record uses); after each gather every rank holds the whole batch, identical to one oracle run."""
+    steps, seed = 30, 17
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    idfile = str(tmp_path / "uid")
+    outs = [str(tmp_path / f"out{r}.npz") for r in range(world)]
+    env = dict(os.environ, DRONE_RCCL_LIB=stub)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(total), str(task), str(steps), str(seed), idfile, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=4)
+    o.reset(seed)
+    for _ in range(steps):
+        o.fill_random_actions()
+        o.step()
+    for r in range(world):
+        g = np.load(outs[r])
+        assert g["obs"].tobytes() == o.observations.tobytes(), f"rank {r}: observations"
+        assert g["rew"].tobytes() == o.rewards.tobytes(), f"rank {r}: rewards"
+        assert g["term"].tobytes() == o.terminals.tobytes() and g["trunc"].tobytes() == o.truncations.tobytes(), f"rank {r}: flags"
