@@ -226,3 +226,34 @@ def test_sweep_orders_are_bijective(oracle, hip, monkeypatch, order, n):
     o.rollout(17)
     h.rollout(17)
     assert_state_equal(o.get_state(), h.get_state(), f"order {order} state after rollout")
+
+
+@pytest.mark.parametrize("task", [0, 1, 3])
+def test_state_rows_on_unaligned_subranges(hip, task):
+    """get_state / set_state address the tiled layout ([tile of 64][plane][lane]): ranges that start and end inside a
+    tile must touch exactly their rows (the edge tiles are fetched, patched and written back)."""
+    n = 1000
+    h = hip.DroneVec(n, seed=3, task=task, device="cuda:0")
+    h.reset(3)
+    for _ in range(5):
+        h.fill_random_actions()
+        h.step()
+    full = h.get_state()
+    rng = np.random.default_rng(0)
+    for first, count in ((0, 1), (63, 2), (1, 62), (65, 130), (100, 900), (999, 1), (0, 1000), (37, 0)):
+        part = h.get_state(first, count)
+        assert part.tobytes() == full[first:first + count].tobytes(), (first, count)
+        patch = part.copy()
+        for f in ("pos", "vel", "omega", "rpm", "target", "ep_return", "perf_sum", "n_sum"):
+            patch[f] = rng.standard_normal(patch[f].shape).astype(np.float32)
+        patch["tick"] = rng.integers(0, 100, size=count, dtype=np.uint32)
+        patch["episode"] = rng.integers(0, 1 << 31, size=count, dtype=np.uint32)
+        if task == 0:
+            patch["wind"] = 0  # hover tiles carry no aux plane: wind reads back as zero
+        h.set_state(patch, first)
+        now = h.get_state()
+        want = full.copy()
+        want[first:first + count] = patch
+        assert now.tobytes() == want.tobytes(), (first, count)
+        full = want
+    h.close()
