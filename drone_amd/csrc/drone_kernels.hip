@@ -155,7 +155,7 @@ __device__ __forceinline__ void state_store(float4* p, const float4& v) {
 }
 
 // A scattered 16-byte store into HBM is a partial-line write: the memory controller turns it into a read-modify-write
-// that holds its channel ~100 ns (measured: one such store per ended episode, 0.8 % of the lanes, cost 5 % of the
+// that occupies its channel for tens of nanoseconds (measured: one such store per ended episode, 0.8 % of the lanes, cost 5 % of the
 // step kernel at 2^22 envs; profiles/r02_ab/ab_ends_*.txt). So rare per-lane plane updates are widened to whole
 // 128-byte lines: if any of the 8 lanes that share a line needs the update, all 8 store (the others rewrite what they
 // hold). `m` is a ballot mask; the result has every aligned group of 8 bits set in which `m` had a bit. While the
