@@ -103,6 +103,7 @@ SYMBOLS = {
     "drone_vec_gstep": (C.c_uint32, [_P]),
     "drone_vec_num_envs": (C.c_int, [_P]),
     "drone_vec_set_gstep": (C.c_int, [_P, C.c_uint32]),
+    "drone_vec_enable_graph_capture": (C.c_int, [_P, C.c_int]),
     "drone_vec_status": (C.c_int, [_P]),
     "drone_vec_status_message": (C.c_char_p, [_P]),
     "drone_vec_clear_status": (None, [_P]),

@@ -219,6 +219,10 @@ class DroneVec:
     def gstep(self):
         return self._f["drone_vec_gstep"](self._h)
 
+    def enable_graph_capture(self, on=True):
+        """Counters in HBM, advanced by the kernels: a captured step / rollout (torch.cuda.graph) replays correctly."""
+        self._check(self._f["drone_vec_enable_graph_capture"](self._h, 1 if on else 0))
+
     def set_gstep(self, gstep):
         self._check(self._f["drone_vec_set_gstep"](self._h, int(gstep)))
 

@@ -27,6 +27,7 @@ struct DeviceView {
     unsigned char* trunc;// [n]
     unsigned long long* stamps; // diagnostic builds only (-DDRONE_STAMPS=1): [waves][kStampSlots] clock stamps, else null
     float* pad_sink;     // [kBlock] floats: where the padding lanes [n, n_pad) of the last workgroup drop their reward
+    uint32_t* ctr;       // graph-safe stepping: {gstep, step launches, workgroup arrivals} in HBM, or null (counters are launch arguments)
     uint32_t* done_ids;  // [n] or null
     uint32_t* done_count;// [2] ping-pong per step launch, or null
 };

@@ -408,6 +408,32 @@ __device__ __forceinline__ void obs_any(const KParams& P, const Lane& L, float4*
     }
 }
 
+// Graph-safe stepping (drone_vec_enable_graph_capture): the vec-level step counter and the step-launch counter live
+// in HBM (ctr[0], ctr[1]) instead of in the launch arguments, so that a captured launch replays with advancing
+// counters. Every workgroup reads them at its start; the LAST workgroup to finish (arrival counter ctr[2]) advances
+// them — by then every other workgroup of this launch has read them — and the kernel boundary publishes the new
+// values to the next launch. One extra scalar-memory round trip per wave and one atomic per workgroup: off by default.
+struct Counters {
+    uint32_t gstep, launches;
+};
+__device__ __forceinline__ Counters read_counters(const StepArgs& a) {
+    Counters c = {a.gstep, a.done_slot};
+    if (a.v.ctr) {  // launch-uniform
+        c.gstep = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.v.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        c.launches = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.v.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return c;
+}
+__device__ __forceinline__ void advance_counters(const StepArgs& a, const Counters& c, uint32_t steps, uint32_t launches) {
+    if (a.v.ctr && threadIdx.x == 0) {
+        if (atomicAdd(&a.v.ctr[2], 1u) == gridDim.x - 1u) {  // the last workgroup of this launch
+            a.v.ctr[2] = 0u;
+            a.v.ctr[0] = c.gstep + steps;
+            a.v.ctr[1] = c.launches + launches;
+        }
+    }
+}
+
 // which 256-drone chunk this workgroup owns. `order` (a launch argument, chosen by the host from the step's
 // footprint; DeviceView::order) — bit 0: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the
 // envs instead of being dealt round-robin over one global sweep; bit 2: non-temporal action loads (load_raw);
@@ -449,7 +475,9 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     float4* const tile = sh.obs_tile[threadIdx.x / kWave];
     // This workgroup walks DRONE_STEP_TILES consecutive 256-drone chunks. Lanes [n, n_pad) exist in the planes
     // and hold a valid reset state: they load and compute like the rest and store nothing.
-    uint32_t block_base = my_chunk(a.v.order, a.gstep) * (uint32_t)(DRONE_STEP_TILES * kBlock);
+    const Counters ctr = read_counters(a);
+    const uint32_t gstep = ctr.gstep, done_slot = ctr.launches & 1u;
+    uint32_t block_base = my_chunk(a.v.order, gstep) * (uint32_t)(DRONE_STEP_TILES * kBlock);
 #if DRONE_STAMPS
     unsigned long long stamp_[kStampSlots];
     stamp_[8] = __builtin_amdgcn_s_memrealtime();
@@ -457,7 +485,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
     load_raw<TASK, STREAM>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
-    if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[a.done_slot ^ 1u] = 0u;  // arm the next step launch's counter
+    if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
 #pragma unroll
     for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
         const uint32_t i = block_base + threadIdx.x;
@@ -478,7 +506,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
 #endif
         DRONE_STAMP(2);  // data arrived
         StepOut out;
-        step_any<TASK>(P, L, tile, act, P.env_offset + i, a.gstep, out);
+        step_any<TASK>(P, L, tile, act, P.env_offset + i, gstep, out);
 #if DRONE_STAMPS
         asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.q[0]), "v"(out.reward));
 #endif
@@ -509,7 +537,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
             const uint64_t m_done = __ballot(done);
             if (m_done != 0) {  // wave-uniform
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.v.done_count + a.done_slot, (uint32_t)__popcll(m_done));
+                if (lane == 0) base = atomicAdd(a.v.done_count + done_slot, (uint32_t)__popcll(m_done));
                 base = __shfl(base, 0);
                 if (done) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
@@ -549,6 +577,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         if (!more) break;
         cur = nxt;
     }
+    advance_counters(a, ctr, 1u, 1u);
 }
 
 // =====================================================================
@@ -595,6 +624,8 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
+    const Counters ctr = read_counters(a);
+    const uint32_t gstep0 = ctr.gstep;
     const uint32_t block_base = my_chunk(a.v.order & 1u, 0u) * kBlock;
     const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
@@ -606,9 +637,9 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     bool any_term = false, any_trunc = false, any_target = false;
     for (uint32_t t = 0; t < horizon; t++) {
         float act[4];
-        random_action(P.key_action, env, a.gstep + t, act);
+        random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, a.gstep + t, out);
+        step_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -625,6 +656,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     float o[DRONE_OBS_DIM_MAX];
     obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
     write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, any_term, any_trunc, i, block_base);
+    advance_counters(a, ctr, horizon, 0u);  // a rollout builds no done-id list: the step-launch counter stays
 }
 
 // =====================================================================

@@ -146,6 +146,25 @@ uint32_t plane_pad_elems() {
     return 0;
 }
 
+// graph-safe stepping: the device copies of the counters ({gstep, step launches, arrivals}); the host fields mirror them
+bool push_counters(DroneVec* v) {
+    if (!v->dv.ctr) return true;
+    const uint32_t c[3] = {v->gstep, v->step_launches, 0u};
+    HIP_TRY(hipMemcpyAsync(v->dv.ctr, c, sizeof(c), hipMemcpyHostToDevice, v->stream), return false);
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);  // `c` is on the stack
+    return true;
+}
+bool pull_counters(DroneVec* v) {
+    if (!v->dv.ctr) return true;
+    uint32_t c[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(c, v->dv.ctr, sizeof(c), hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);
+    if (c[1] != v->step_launches) v->list_valid = true;  // steps ran (e.g. graph replays) since the host last looked
+    v->gstep = c[0];
+    v->step_launches = c[1];
+    return true;
+}
+
 bool upload_params(DroneVec* v) {
     derive_kparams(v->cfg, v->seed, v->kp);
     HIP_TRY(hipMemcpyAsync(v->d_kp, &v->kp, sizeof(KParams), hipMemcpyHostToDevice, v->stream), return false);
@@ -524,7 +543,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->gstep = 0;
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
     v->list_valid = false;
-    if (!upload_params(v)) return;
+    if (!upload_params(v) || !push_counters(v)) return;
     HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream), return);
     if (v->host_buffers) device_to_host_outputs(v);
 }
@@ -586,6 +605,7 @@ void drone_vec_close(DroneVec* v) {
     (void)hipFree(v->dv.cold);
     (void)hipFree(v->d_kp);
     (void)hipFree(v->dv.pad_sink);
+    (void)hipFree(v->dv.ctr);
     (void)hipFree(v->dv.stamps);
     (void)hipFree(v->d_partials);
     if (v->h_partials) (void)hipHostFree(v->h_partials);
@@ -670,13 +690,37 @@ int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep) {
     return 0;
 }
 
-uint32_t drone_vec_gstep(const DroneVec* v) { return v ? v->gstep : 0u; }
+uint32_t drone_vec_gstep(const DroneVec* v) {
+    if (!v) return 0u;
+    if (v->dv.ctr) {  // graph-safe stepping: the device owns the counter (replays advance it without a host call)
+        Entry in(v);
+        if (in) (void)pull_counters(const_cast<DroneVec*>(v));
+    }
+    return v->gstep;
+}
 
 int drone_vec_set_gstep(DroneVec* v, uint32_t gstep) {
     Entry in(v);
     if (!in) return -1;
+    if (!pull_counters(v)) return -1;  // keep the device's step-launch count
     v->gstep = gstep;
     v->list_valid = false;
+    return push_counters(v) ? 0 : -1;
+}
+
+int drone_vec_enable_graph_capture(DroneVec* v, int on) {
+    Entry in(v);
+    if (!in) return -1;
+    if (v->host_buffers) { set_err("graph-safe stepping needs device buffers (host-buffer steps end in a stream sync, which cannot be captured)"); return -1; }
+    if (on && !v->dv.ctr) {
+        HIP_TRY(hipMalloc((void**)&v->dv.ctr, 3 * sizeof(uint32_t)), return -1);
+        if (!push_counters(v)) return -1;
+    } else if (!on && v->dv.ctr) {
+        if (!pull_counters(v)) return -1;
+        HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+        (void)hipFree(v->dv.ctr);
+        v->dv.ctr = nullptr;
+    }
     return 0;
 }
 
@@ -795,6 +839,7 @@ int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap) {
     Entry in(v);
     if (!in) return -1;
     if (!v->dv.done_ids) { set_err("done list not enabled (compact_done=0)"); return -1; }
+    if (!pull_counters(v)) return -1;
     if (!v->list_valid || v->step_launches == 0) return 0;  // after reset / after a fused rollout there is no list
     uint32_t cnt = 0;
     HIP_TRY(hipMemcpyAsync(&cnt, v->dv.done_count + ((v->step_launches - 1u) & 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, v->stream), return -1);

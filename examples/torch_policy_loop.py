@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Device-resident RL loop: a small torch-ROCm MLP policy reads the env's
 observation tensor in HBM and writes the action tensor the env reads — no host
-copies, one stream. Prints env-steps/s including the policy.
+copies, one stream. Prints env-steps/s including the policy,
+first launched eagerly (a dozen launches per step: host-bound at small shards),
+then with "policy forward + env step" captured ONCE into a hipGraph
+(torch.cuda.graph) and replayed: graph-safe stepping (drone_vec_enable_graph_capture)
+keeps the step counter in HBM so the replays advance it.
 
     python examples/torch_policy_loop.py [--envs 65536] [--steps 500] [--task hover]
 """
@@ -46,6 +50,35 @@ def main():
     print(f"{a.envs} envs x {a.steps} steps with a 20-{a.hidden}-{a.hidden}-4 tanh MLP policy on the same stream: "
           f"{a.envs * a.steps / el:.3e} env-steps/s ({el * 1e6 / a.steps:.1f} us per step); "
           f"episodes {log['n']:.0f}, mean return {log['episode_return']:.3f}, mean length {log['episode_length']:.1f}")
+
+    # the same loop as ONE captured graph per step
+    vec = env.vec
+    vec.enable_graph_capture(True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            vec.use_torch_stream()
+            for _ in range(3):
+                vec.actions.copy_(policy(vec.observations))
+                vec.step()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            vec.use_torch_stream()
+            vec.actions.copy_(policy(vec.observations))
+            vec.step()
+        g0 = vec.gstep
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            g.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    assert vec.gstep == g0 + a.steps
+    log = vec.log()
+    print(f"captured as one hipGraph per step and replayed: {a.envs * a.steps / el:.3e} env-steps/s ({el * 1e6 / a.steps:.1f} us per step); "
+          f"episodes {log['n']:.0f}, mean return {log['episode_return']:.3f}")
     env.close()
 
 

@@ -145,6 +145,14 @@ int drone_vec_num_envs(const DroneVec* v);
  * set_gstep continues bit for bit like the uninterrupted one. */
 int drone_vec_set_gstep(DroneVec* v, uint32_t gstep);
 
+/* Graph-safe stepping. By default the step counter travels in the launch arguments, so a drone_vec_step captured into
+ * a hipGraph (hipStreamBeginCapture on the handle's stream — e.g. torch.cuda.graph around "policy forward + env step")
+ * would replay with a frozen counter. After drone_vec_enable_graph_capture(v, 1) the counters live in HBM and the
+ * kernels advance them themselves, so a captured step / rollout replays correctly (device buffers only; the bound
+ * action / output pointers are baked into the capture like any graph argument). drone_vec_gstep and drone_vec_done_list
+ * then read the device counters (a stream sync). Costs one more memory round trip per wave: off by default. */
+int drone_vec_enable_graph_capture(DroneVec* v, int on);
+
 /* Sticky status of the handle. reset / step / rollout / log return void (the
  * PufferLib convention), so a failed launch or copy would otherwise go
  * unnoticed: the FIRST failure of any call on the handle is kept here until

@@ -60,7 +60,7 @@ def lib():
         _lib = C.CDLL(_SO)
         names = [n for n in abi.SYMBOLS if n not in (
             "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_bind_outputs", "drone_vec_done_list",
-            "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error", "drone_device_count", "drone_vec_set_gstep", "drone_vec_status",
+            "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error", "drone_device_count", "drone_vec_set_gstep", "drone_vec_enable_graph_capture", "drone_vec_status",
             "drone_vec_status_message", "drone_vec_clear_status", "drone_gather_unique_id", "drone_vec_gather_init",
             "drone_vec_gather", "drone_vec_gather_close")]
         _fns = abi.bind(_lib, prefix_to="oracle_", names=names)
