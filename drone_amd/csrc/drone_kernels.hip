@@ -722,9 +722,15 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
 
 inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
+// hipGetLastError() reports the calling thread's last runtime error, whoever caused it (another library's call that
+// failed benignly, a query that returned not-ready). Drop anything stale first so that what a launch_* returns is
+// the launch's own status.
+inline void drop_stale_error() { (void)hipGetLastError(); }
+
 }  // namespace
 
 hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
+    drop_stale_error();
     const dim3 g(v.n_pad / kBlock), b(kBlock);
     if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(make_args(v, 0));
     else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(make_args(v, 0));
@@ -734,6 +740,7 @@ hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
 }
 
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s) {
+    drop_stale_error();
     StepArgs a = make_args(v, gstep);
     a.done_slot = done_slot & 1u;
     const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
@@ -753,6 +760,7 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
 }
 
 hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s) {
+    drop_stale_error();
     const StepArgs a = make_args(v, gstep0);
     const dim3 g(grid_for(v.n)), b(kBlock);
     if (task == DRONE_TASK_HOVER) drone_rollout_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(a, horizon);
@@ -763,11 +771,13 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
 }
 
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s) {
+    drop_stale_error();
     drone_fill_actions_kernel<<<dim3(grid_for(v.n)), dim3(kBlock), 0, s>>>(make_args(v, gstep), reinterpret_cast<float4*>(actions));
     return hipGetLastError();
 }
 
 hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid, int* grid_out, hipStream_t s) {
+    drop_stale_error();
     int g = (int)grid_for(v.n);
     if (g > max_grid) g = max_grid;
     *grid_out = g;

@@ -250,6 +250,15 @@ void* mapped_ptr(void* host) {
     return d;
 }
 
+// A caller that rebinds away from a buffer we pinned at init may free it right away; a pin left on freed pages makes
+// any later copy that touches those addresses again fail ("invalid argument": a range that is only partly pinned).
+void unpin_if_rebound(DroneVec* v, int slot, const void* now) {
+    if (v->registered[slot] && v->registered_ptr[slot] != now) {
+        (void)hipHostUnregister(v->registered_ptr[slot]);
+        v->registered[slot] = false;
+    }
+}
+
 void leave_zero_copy(DroneVec* v) {
     v->zero_copy = false;
     v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
@@ -647,6 +656,7 @@ int drone_vec_bind_actions(DroneVec* v, float* actions) {
     if (!v || !actions) { set_err("bind_actions: NULL argument"); return -1; }
     if (v->host_buffers) {
         if (v->zero_copy && actions != v->u_act) leave_zero_copy(v);  // an unregistered buffer: back to the mirror transport
+        unpin_if_rebound(v, 1, actions);
         v->u_act = actions;  // copied (pageable unless the caller pinned it) at the next step
     } else {
         if (reinterpret_cast<uintptr_t>(actions) & 15u) { set_err("actions must be 16-byte aligned"); return -1; }
@@ -670,6 +680,12 @@ int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, uns
     // (pageable unless the caller pinned them)
     if (v->host_buffers && v->zero_copy && (observations != v->u_obs || rewards != v->u_rew || terminals != v->u_term || truncations != v->u_trunc))
         leave_zero_copy(v);
+    if (v->host_buffers) {
+        unpin_if_rebound(v, 0, observations);
+        unpin_if_rebound(v, 2, rewards);
+        unpin_if_rebound(v, 3, terminals);
+        unpin_if_rebound(v, 4, truncations);
+    }
     v->u_obs = observations; v->u_rew = rewards; v->u_term = terminals; v->u_trunc = truncations;
     return 0;
 }
