@@ -93,6 +93,7 @@ SYMBOLS = {
     "drone_vec_reset": (None, [_P, C.c_uint64]),
     "drone_vec_step": (None, [_P]),
     "drone_vec_rollout": (None, [_P, C.c_int]),
+    "drone_vec_step_many": (None, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "drone_vec_log": (None, [_P, C.POINTER(DroneLog)]),
     "drone_vec_close": (None, [_P]),
     "drone_vec_set_stream": (C.c_int, [_P, _P]),
@@ -114,6 +115,7 @@ SYMBOLS = {
     "drone_vec_get_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "drone_vec_set_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "drone_vec_done_list": (C.c_int, [_P, _P, C.c_int]),
+    "drone_vec_done_list_at": (C.c_int, [_P, C.c_int, _P, C.c_int]),
     "drone_vec_timer_start": (C.c_int, [_P]),
     "drone_vec_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "drone_last_error": (C.c_char_p, []),

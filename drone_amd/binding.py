@@ -83,6 +83,15 @@ def load_variant(path):
     return abi.bind(C.CDLL(path))
 
 
+class StepManyBuffers:
+    """The K-major blocks of one ``step_many`` call: actions [K][N][4] in, observations [K][N][O] / rewards [K][N] /
+    terminals [K][N] / truncations [K][N] out (numpy for host-buffer handles, torch tensors in HBM otherwise)."""
+
+    def __init__(self, k_steps, actions, observations, rewards, terminals, truncations):
+        self.k_steps = int(k_steps)
+        self.actions, self.observations, self.rewards, self.terminals, self.truncations = actions, observations, rewards, terminals, truncations
+
+
 class DroneVec:
     """One shard of envs on one GPU.
 
@@ -196,6 +205,40 @@ class DroneVec:
     def rollout(self, horizon):
         self._f["drone_vec_rollout"](self._h, int(horizon))
         self._raise_if_failed()
+
+    def alloc_step_many(self, k_steps):
+        """Blocks of the handle's buffer kind for ``step_many`` (allocate once, reuse every call)."""
+        n, od, K = self.num_envs, abi.obs_dim(self.cfg.task), int(k_steps)
+        if self.torch_device is None:
+            return StepManyBuffers(K, np.zeros((K, n, abi.ACT_DIM), np.float32), np.zeros((K, n, od), np.float32), np.zeros((K, n), np.float32),
+                                   np.zeros((K, n), np.uint8), np.zeros((K, n), np.uint8))
+        import torch
+
+        dev = self.torch_device
+        return StepManyBuffers(K, torch.zeros((K, n, abi.ACT_DIM), dtype=torch.float32, device=dev), torch.zeros((K, n, od), dtype=torch.float32, device=dev),
+                               torch.zeros((K, n), dtype=torch.float32, device=dev), torch.zeros((K, n), dtype=torch.uint8, device=dev),
+                               torch.zeros((K, n), dtype=torch.uint8, device=dev))
+
+    def step_many(self, bufs, policy=False):
+        """K env steps in one launch with every step's outputs (``drone_vec_step_many``): reads ``bufs.actions`` (or,
+        with ``policy=True``, draws the SPEC.md random policy in the kernel) and fills the four output blocks."""
+        n, od, K = self.num_envs, abi.obs_dim(self.cfg.task), bufs.k_steps
+        for t, shape in ((bufs.actions, (K, n, abi.ACT_DIM)), (bufs.observations, (K, n, od)), (bufs.rewards, (K, n)), (bufs.terminals, (K, n)), (bufs.truncations, (K, n))):
+            if tuple(t.shape) != shape or _is_torch(t) != (self.torch_device is not None):
+                raise ValueError(f"step_many block of shape {tuple(t.shape)}, expected {shape} of the handle's buffer kind")
+        self._f["drone_vec_step_many"](self._h, K, None if policy else _ptr(bufs.actions), _ptr(bufs.observations), _ptr(bufs.rewards),
+                                       _ptr(bufs.terminals), _ptr(bufs.truncations))
+        if self._status(self._h):
+            self._raise_if_failed()
+        return bufs
+
+    def done_list_at(self, k):
+        """ids of the envs that finished in step ``k`` of the last ``step_many`` (compact_done=1)."""
+        ids = np.zeros(self.num_envs, dtype=np.uint32)
+        cnt = self._f["drone_vec_done_list_at"](self._h, int(k), ids.ctypes.data, self.num_envs)
+        if cnt < 0:
+            raise RuntimeError("libdrone_hip: " + self._f["drone_last_error"]().decode())
+        return ids[:cnt]
 
     def log(self):
         out = abi.DroneLog()

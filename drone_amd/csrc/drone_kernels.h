@@ -42,6 +42,10 @@ hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s);
 // done_slot: which done_count slot this launch adds to (compact_done); the kernel zeroes the other one for the next step launch
 hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s);
 hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s);
+// K env steps in one launch with per-step outputs into [K][n]... blocks; act == nullptr: the random policy in-kernel;
+// done_ids [K][n] + done_count [K] (zeroed by the caller on the same stream) or both null
+hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, float* obs, float* rew,
+                            unsigned char* term, unsigned char* trunc, uint32_t* done_ids, uint32_t* done_count, hipStream_t s);
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s);
 // partials: [grid][6] doubles; returns grid size via *grid_out. Clears the log planes.
 hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid, int* grid_out, hipStream_t s);

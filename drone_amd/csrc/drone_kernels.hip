@@ -660,6 +660,168 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
 }
 
 // =====================================================================
+// K env steps per launch WITH per-step outputs (drone_vec_step_many).
+// Between the per-step kernel (state through HBM every step, one dependent
+// launch boundary per step) and the fused rollout (outputs only at the
+// horizon): state is read once, stays in registers for K steps and is written
+// once; every step reads its action row from the caller's [K][N][4] block (or
+// draws it from the counter-RNG policy when there is none) and writes its
+// observation rows / reward / flag bytes into the caller's [K][N]... blocks,
+// exactly what K calls of drone_vec_step would have left there. What it buys:
+// at small shards the 2.5 us dependent-launch boundary and the per-launch
+// prologue are paid once per K steps instead of once per step (65 536 envs:
+// 5.2 us per step -> profiles/r03_step_many_65536/), at large ones the state
+// planes leave the per-step byte count (hover: 278 -> 102 + 176 / K bytes).
+// The next step's action row is requested before this step's arithmetic, so its
+// latency hides behind ~450 VALU instructions; vmcnt retires in order, so the
+// row is consumed one iteration later with this iteration's stores still in
+// flight (the first iteration is peeled by hand to give the loop entry the same
+// outstanding-store count as the back edge — at a join the wait-count pass
+// keeps the more conservative of the two).
+// =====================================================================
+struct ManyArgs {
+    const float* act;      // [K][n][4], or null: the SPEC.md section 2 random policy, drawn in the kernel
+    float* obs;            // [K][n][obs_dim]
+    float* rew;            // [K][n]
+    unsigned char* term;   // [K][n]
+    unsigned char* trunc;  // [K][n]
+    uint32_t* done_ids;    // [K][n] (compact_done) or null
+    uint32_t* done_count;  // [K], zeroed by the host before the launch
+    uint32_t k_steps;
+};
+
+// A FULL wave's outputs of one step, on ONE static path with a fixed number of vector-memory operations and no
+// workgroup barrier: the wait-count pass keeps, at every join, the most conservative outstanding-store count of the
+// joined paths, and the exec-skip branch the compiler puts around any divergent store is such a path — a single
+// guarded store in the loop body makes the wait for the prefetched action row drain the previous step's stores.
+// So: every lane stores, always. Observation rows as in write_outputs (wave-private LDS transpose, OBSV x 1 KiB).
+// Flag bytes per wave instead of per workgroup (no LDS masks, no barrier): the wave's 64 + 64 bytes leave as eight
+// 16-byte pieces; all 64 lanes take part, lanes l and l + 8k writing the same bytes to the same address.
+template <int OBSV>
+__device__ __forceinline__ void write_outputs_wave(float4* tile, float* obs_wave, unsigned char* term_wave, unsigned char* trunc_wave, bool flags16,
+                                                   const float (&o)[DRONE_OBS_DIM_MAX], bool term, bool trunc) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t m_term = __ballot(term);
+    const uint64_t m_trunc = __ballot(trunc);
+#pragma unroll
+    for (int k = 0; k < OBSV; k++) tile[lane * OBSV + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4* dst = reinterpret_cast<float4*>(obs_wave);
+    float4 piece[OBSV];
+#pragma unroll
+    for (int k = 0; k < OBSV; k++) piece[k] = tile[k * kWave + lane];
+#pragma unroll
+    for (int k = 0; k < OBSV; k++) out_store(&dst[k * kWave + lane], piece[k]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads are done before the tile is written again
+    __builtin_amdgcn_wave_barrier();
+    if (flags16) {  // launch-uniform: both flag blocks and the env count are 16-byte multiples
+        const uint32_t which = (lane >> 2) & 1u, j = lane & 3u;
+        const uint32_t bits = (uint32_t)((which ? m_trunc : m_term) >> (j * 16u)) & 0xFFFFu;
+        const u4_t packed = {spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12)};
+        out_store(reinterpret_cast<u4_t*>(which ? trunc_wave : term_wave) + j, packed);
+    } else {
+        term_wave[lane] = term ? 1 : 0;
+        trunc_wave[lane] = trunc ? 1 : 0;
+    }
+}
+
+// one env step of the K: everything between "action row in registers" and "outputs of step k issued".
+// FULL: every lane of this workgroup is a real env (all but the last workgroup of a ragged shard).
+template <int TASK, bool COMPACT, bool POLICY, bool FULL>
+__device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const StepArgs& a, const ManyArgs& m, Lane& L, float4& l0, float4& l1,
+                                          const float4& arow, uint32_t k, uint32_t gstep, uint32_t i, uint32_t block_base, bool& any_target, bool& any_end) {
+    const uint32_t n = a.v.n;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const bool valid = FULL || i < n;
+    float4* const tile = sh.obs_tile[threadIdx.x / kWave];
+    const uint32_t env = P.env_offset + i;
+    float act[4];
+    if (POLICY) random_action(P.key_action, env, gstep, act);
+    else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
+    StepOut out;
+    step_any<TASK>(P, L, tile, act, env, gstep, out);
+    const bool ended = out.oob || out.trunc;
+    any_target |= out.target_changed;
+    any_end |= ended;
+    if (ended) fold_log(l0, l1, out);  // log sums stay in registers; written once at the end of the launch
+    const size_t row0 = (size_t)k * n;  // first row of step k in the caller's [K][n] blocks
+    out_store(valid ? &m.rew[row0 + i] : &a.v.pad_sink[threadIdx.x], out.reward);
+    if (COMPACT) {  // per-step done-id list: ballot -> one atomic per wave -> mbcnt rank
+        const uint64_t m_done = __ballot(valid && ended);
+        if (m_done != 0) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(m.done_count + k, (uint32_t)__popcll(m_done));
+            base = __shfl(base, 0);
+            if (valid && ended) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
+                m.done_ids[row0 + base + rank] = i;
+            }
+        }
+    }
+    float o[DRONE_OBS_DIM_MAX];
+    obs_any<TASK>(P, L, tile, o);
+    constexpr int OBSV = obs_vec<TASK>();
+    if (FULL) {
+        const uint32_t wave_base = i - lane;
+        // 16-byte flag pieces need step k's slices 16-byte aligned: block bases aligned and n a multiple of 16 (launch-uniform)
+        const bool flags16 = ((reinterpret_cast<uintptr_t>(m.term) | reinterpret_cast<uintptr_t>(m.trunc) | (uintptr_t)n) & 15u) == 0;
+        write_outputs_wave<OBSV>(tile, m.obs + (row0 + wave_base) * (size_t)(4 * OBSV), m.term + row0 + wave_base, m.trunc + row0 + wave_base, flags16, o, out.oob, out.trunc);
+    } else {
+        DeviceView w = a.v;  // step k's slices of the caller's blocks (only the output pointers differ)
+        w.obs = m.obs + row0 * (size_t)(4 * OBSV);
+        w.term = m.term + row0;
+        w.trunc = m.trunc + row0;
+        const uint32_t fa = ((reinterpret_cast<uintptr_t>(w.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(w.trunc) & 15u) == 0 ? 2u : 0u);
+        write_outputs<OBSV>(sh, w, fa, o, out.oob, out.trunc, i, block_base, k & 1u);
+    }
+}
+
+template <int TASK, bool COMPACT, bool POLICY, bool FULL>
+__device__ __forceinline__ void many_loop(const KParams& P, Shared& sh, const StepArgs& a, const ManyArgs& m, Lane& L, float4& l0, float4& l1,
+                                          uint32_t gstep0, uint32_t i, uint32_t block_base, bool& any_target, bool& any_end) {
+    const uint32_t n = a.v.n, K = m.k_steps;
+    // action rows: lane i's row of step k is actp[k * n]; lanes >= n read the last env's row and store nothing
+    const float4* actp = POLICY ? nullptr : reinterpret_cast<const float4*>(m.act) + (FULL ? i : min(i, n - 1u));
+    float4 a_cur = make_float4(0.f, 0.f, 0.f, 0.f), a_nxt = a_cur;
+    if (!POLICY) {
+        a_cur = actp[0];
+        a_nxt = actp[(size_t)min(1u, K - 1u) * n];
+    }
+    // step 0, peeled: the loop below is entered with step 0's stores behind the load of a_nxt, like every later entry
+    many_step<TASK, COMPACT, POLICY, FULL>(P, sh, a, m, L, l0, l1, a_cur, 0u, gstep0, i, block_base, any_target, any_end);
+    for (uint32_t k = 1; k < K; k++) {
+        a_cur = a_nxt;
+        if (!POLICY) a_nxt = actp[(size_t)min(k + 1u, K - 1u) * n];  // the NEXT step's row: in flight during this step's arithmetic
+        many_step<TASK, COMPACT, POLICY, FULL>(P, sh, a, m, L, l0, l1, a_cur, k, gstep0 + k, i, block_base, any_target, any_end);
+    }
+}
+
+template <int TASK, bool COMPACT, bool POLICY>
+__global__ __launch_bounds__(kBlock) void drone_step_many_kernel(StepArgs a, ManyArgs m) {
+    __shared__ Shared sh;
+    const KParams& P = DRONE_PARAMS(sh, a);
+    const uint32_t n = a.v.n, np = a.v.stride;
+    const Counters ctr = read_counters(a);
+    const uint32_t block_base = my_chunk(a.v.order & 1u, 0u) * kBlock;
+    const uint32_t i = block_base + threadIdx.x;
+    Lane L;
+    load_lane<TASK>(a.v.planes, a.v.n_pad, i, L);
+    float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
+    bool any_target = false, any_end = false;
+    if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
+    else many_loop<TASK, COMPACT, POLICY, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard
+    // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)));
+    if (lane_bit(whole_lines(__ballot(any_end), a.v.line_complete))) {
+        a.v.cold[i] = l0;
+        a.v.cold[np + i] = l1;
+    }
+    advance_counters(a, ctr, m.k_steps, 0u);  // the per-step done-list ping-pong of drone_vec_step is not touched
+}
+
+// =====================================================================
 // synthetic random policy into an action buffer (bench / tests)
 // =====================================================================
 __global__ __launch_bounds__(kBlock) void drone_fill_actions_kernel(StepArgs a, float4* __restrict__ actions) {
@@ -767,6 +929,28 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     else if (task == DRONE_TASK_SWARM) drone_rollout_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(a, horizon);
     else if (task == DRONE_TASK_RACE) drone_rollout_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(a, horizon);
     else drone_rollout_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(a, horizon);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, float* obs, float* rew,
+                            unsigned char* term, unsigned char* trunc, uint32_t* done_ids, uint32_t* done_count, hipStream_t s) {
+    drop_stale_error();
+    const StepArgs a = make_args(v, gstep0);
+    ManyArgs m;
+    m.act = act; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
+    m.done_ids = done_ids; m.done_count = done_count; m.k_steps = k_steps;
+    const dim3 g(grid_for(v.n)), b(kBlock);
+    const bool compact = done_ids != nullptr, policy = act == nullptr;
+#define DRONE_LAUNCH_MANY(T)                                                                 \
+    do {                                                                                     \
+        if (compact) { if (policy) drone_step_many_kernel<T, true, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, true, false><<<g, b, 0, s>>>(a, m); } \
+        else { if (policy) drone_step_many_kernel<T, false, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, false, false><<<g, b, 0, s>>>(a, m); }    \
+    } while (0)
+    if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_MANY(DRONE_TASK_HOVER);
+    else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_MANY(DRONE_TASK_SWARM);
+    else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_MANY(DRONE_TASK_RACE);
+    else DRONE_LAUNCH_MANY(DRONE_TASK_WAYPOINT);
+#undef DRONE_LAUNCH_MANY
     return hipGetLastError();
 }
 

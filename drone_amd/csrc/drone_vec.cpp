@@ -91,6 +91,14 @@ struct DroneVec {
     // fused rollout (which advances gstep but builds no list) cannot desynchronise the ping-pong
     uint32_t step_launches;
     bool list_valid;     // the last path call was drone_vec_step
+    // drone_vec_step_many: per-step done-id lists [many_cap][n] + counts [many_cap] (compact_done), device staging of the
+    // K-major blocks (host-buffer handles), all grown on demand
+    uint32_t* many_ids;
+    uint32_t* many_count;
+    int many_cap;        // steps the list storage holds
+    int many_k;          // k_steps of the last drone_vec_step_many, 0 if the last path call was something else
+    float* s_act; float* s_obs; float* s_rew; unsigned char* s_term; unsigned char* s_trunc;
+    int stage_cap;       // steps the staging blocks hold
     // sticky status: the first failure of any call on this handle (drone_vec_status)
     int status;
     char status_msg[512];
@@ -552,6 +560,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->gstep = 0;
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
     v->list_valid = false;
+    v->many_k = 0;
     if (!upload_params(v) || !push_counters(v)) return;
     HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream), return);
     if (v->host_buffers) device_to_host_outputs(v);
@@ -565,6 +574,7 @@ void drone_vec_step(DroneVec* v) {
     v->gstep += 1;
     v->step_launches += 1;
     v->list_valid = true;
+    v->many_k = 0;
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
@@ -575,7 +585,75 @@ void drone_vec_rollout(DroneVec* v, int horizon) {
     HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream), return);
     v->gstep += (uint32_t)horizon;
     v->list_valid = false;  // the fused rollout builds no done-id list
+    v->many_k = 0;
     if (v->host_buffers) device_to_host_outputs(v);
+}
+
+namespace {
+
+// grow the K-dependent device storage of drone_vec_step_many (drained first: an earlier launch may still use the old blocks)
+bool many_reserve(DroneVec* v, int k_steps) {
+    const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task), K = (size_t)k_steps;
+    if (v->cfg.compact_done && k_steps > v->many_cap) {
+        HIP_TRY(hipStreamSynchronize(v->stream), return false);
+        (void)hipFree(v->many_ids); v->many_ids = nullptr;
+        (void)hipFree(v->many_count); v->many_count = nullptr;
+        v->many_cap = 0;
+        HIP_TRY(hipMalloc((void**)&v->many_ids, sizeof(uint32_t) * K * n), return false);
+        HIP_TRY(hipMalloc((void**)&v->many_count, sizeof(uint32_t) * K), return false);
+        v->many_cap = k_steps;
+    }
+    if (v->host_buffers && k_steps > v->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(v->stream), return false);
+        (void)hipFree(v->s_act); (void)hipFree(v->s_obs); (void)hipFree(v->s_rew); (void)hipFree(v->s_term); (void)hipFree(v->s_trunc);
+        v->s_act = v->s_obs = v->s_rew = nullptr; v->s_term = v->s_trunc = nullptr;
+        v->stage_cap = 0;
+        HIP_TRY(hipMalloc((void**)&v->s_act, K * n * DRONE_ACT_DIM * sizeof(float)), return false);
+        HIP_TRY(hipMalloc((void**)&v->s_obs, K * n * od * sizeof(float)), return false);
+        HIP_TRY(hipMalloc((void**)&v->s_rew, K * n * sizeof(float)), return false);
+        HIP_TRY(hipMalloc((void**)&v->s_term, K * n), return false);
+        HIP_TRY(hipMalloc((void**)&v->s_trunc, K * n), return false);
+        v->stage_cap = k_steps;
+    }
+    return true;
+}
+
+}  // namespace
+
+void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
+                         unsigned char* terminals, unsigned char* truncations) {
+    Entry in(v);
+    if (!in) return;
+    if (k_steps < 1) { set_err("step_many: k_steps must be positive, got %d", k_steps); return; }
+    if (!observations || !rewards || !terminals || !truncations) { set_err("step_many: NULL output block"); return; }
+    const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task), K = (size_t)k_steps;
+    if (!many_reserve(v, k_steps)) return;
+    const float* d_act = actions;
+    float* d_obs = observations;
+    float* d_rew = rewards;
+    unsigned char* d_term = terminals;
+    unsigned char* d_trunc = truncations;
+    if (v->host_buffers) {
+        d_act = actions ? v->s_act : nullptr;
+        d_obs = v->s_obs; d_rew = v->s_rew; d_term = v->s_term; d_trunc = v->s_trunc;
+        if (actions) HIP_TRY(hipMemcpyAsync(v->s_act, actions, K * n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return);
+    } else if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
+        set_err("step_many: device blocks must be 16-byte aligned (observations, actions) and 4-byte aligned (rewards)");
+        return;
+    }
+    if (v->cfg.compact_done) HIP_TRY(hipMemsetAsync(v->many_count, 0, sizeof(uint32_t) * K, v->stream), return);
+    HIP_TRY(launch_step_many(v->dv, v->cfg.task, v->gstep, (uint32_t)k_steps, d_act, d_obs, d_rew, d_term, d_trunc,
+                             v->cfg.compact_done ? v->many_ids : nullptr, v->cfg.compact_done ? v->many_count : nullptr, v->stream), return);
+    v->gstep += (uint32_t)k_steps;
+    v->list_valid = false;
+    v->many_k = k_steps;
+    if (v->host_buffers) {
+        HIP_TRY(hipMemcpyAsync(observations, v->s_obs, K * n * od * sizeof(float), hipMemcpyDeviceToHost, v->stream), return);
+        HIP_TRY(hipMemcpyAsync(rewards, v->s_rew, K * n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return);
+        HIP_TRY(hipMemcpyAsync(terminals, v->s_term, K * n, hipMemcpyDeviceToHost, v->stream), return);
+        HIP_TRY(hipMemcpyAsync(truncations, v->s_trunc, K * n, hipMemcpyDeviceToHost, v->stream), return);
+        HIP_TRY(hipStreamSynchronize(v->stream), return);
+    }
 }
 
 void drone_vec_log(DroneVec* v, DroneLog* out) {
@@ -620,6 +698,13 @@ void drone_vec_close(DroneVec* v) {
     if (v->h_partials) (void)hipHostFree(v->h_partials);
     (void)hipFree(v->dv.done_ids);
     (void)hipFree(v->dv.done_count);
+    (void)hipFree(v->many_ids);
+    (void)hipFree(v->many_count);
+    (void)hipFree(v->s_act);
+    (void)hipFree(v->s_obs);
+    (void)hipFree(v->s_rew);
+    (void)hipFree(v->s_term);
+    (void)hipFree(v->s_trunc);
     (void)hipFree(v->d_obs);
     (void)hipFree(v->d_act);
     (void)hipFree(v->d_rew);
@@ -851,22 +936,41 @@ int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int c
     return 0;
 }
 
+namespace {
+
+// `cnt_dev`: the device counter of one list, `ids_dev` its ids. The 4-byte count is read and CHECKED after the stream
+// has drained (a stack destination of an async copy holds nothing before that).
+int fetch_done_list(DroneVec* v, const uint32_t* cnt_dev, const uint32_t* ids_dev, uint32_t* ids, int cap) {
+    uint32_t cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, cnt_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, v->stream), return -1);
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    if (cnt > (uint32_t)v->n) { set_err("done list count %u exceeds num_envs %d (corrupt counter)", cnt, v->n); return -1; }
+    const int take = (int)cnt < cap ? (int)cnt : cap;
+    if (ids && take > 0) {
+        HIP_TRY(hipMemcpyAsync(ids, ids_dev, sizeof(uint32_t) * take, hipMemcpyDeviceToHost, v->stream), return -1);
+        HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    }
+    return (int)cnt;
+}
+
+}  // namespace
+
 int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap) {
     Entry in(v);
     if (!in) return -1;
     if (!v->dv.done_ids) { set_err("done list not enabled (compact_done=0)"); return -1; }
     if (!pull_counters(v)) return -1;
     if (!v->list_valid || v->step_launches == 0) return 0;  // after reset / after a fused rollout there is no list
-    uint32_t cnt = 0;
-    HIP_TRY(hipMemcpyAsync(&cnt, v->dv.done_count + ((v->step_launches - 1u) & 1u), sizeof(uint32_t), hipMemcpyDeviceToHost, v->stream), return -1);
-    if (cnt > (uint32_t)v->n) { set_err("done list count %u exceeds num_envs %d (corrupt counter)", cnt, v->n); return -1; }
-    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
-    const int take = (int)cnt < cap ? (int)cnt : cap;
-    if (ids && take > 0) {
-        HIP_TRY(hipMemcpyAsync(ids, v->dv.done_ids, sizeof(uint32_t) * take, hipMemcpyDeviceToHost, v->stream), return -1);
-        HIP_TRY(hipStreamSynchronize(v->stream), return -1);
-    }
-    return (int)cnt;
+    return fetch_done_list(v, v->dv.done_count + ((v->step_launches - 1u) & 1u), v->dv.done_ids, ids, cap);
+}
+
+int drone_vec_done_list_at(DroneVec* v, int k, uint32_t* ids, int cap) {
+    Entry in(v);
+    if (!in) return -1;
+    if (!v->cfg.compact_done) { set_err("done list not enabled (compact_done=0)"); return -1; }
+    if (v->many_k <= 0) { set_err("done_list_at: the last path call was not drone_vec_step_many"); return -1; }
+    if (k < 0 || k >= v->many_k) { set_err("done_list_at: step %d outside the last step_many's %d steps", k, v->many_k); return -1; }
+    return fetch_done_list(v, v->many_count + k, v->many_ids + (size_t)k * (size_t)v->n, ids, cap);
 }
 
 int drone_vec_timer_start(DroneVec* v) {

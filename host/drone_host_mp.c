@@ -8,7 +8,7 @@
  * here: both stay behind the C-ABI.
  *
  *   drone_host_mp [--gpus G] [--envs TOTAL] [--steps K] [--task 0..3] [--seed S]
- *                 [--gather 0|1] [--rollout T] [--crc 1] [--share-devices 1]
+ *                 [--gather 0|1] [--rollout T] [--crc 1] [--share-devices 1] [--timeout SECONDS]
  *
  * Rank r takes envs [offset_r, offset_r + count_r) (the first TOTAL % G ranks get
  * one more) on device r. The RCCL unique id is made by rank 0 AFTER the fork and
@@ -21,7 +21,12 @@
  * --share-devices 1: rank r uses device r %% (visible devices) — lets the fork / shard / barrier logic run with several
  *   ranks on a one-GPU box (without --gather: RCCL refuses two ranks on one device); every rank's CRC over ITS OWN
  *   slice is printed so a test can check each shard against the oracle.
+ * --timeout S (default 300): wall-clock limit of the whole run. The parent reaps its children in ANY order; the first
+ *   abnormal exit (non-zero status, a signal), or the limit, marks the run failed, SIGKILLs the remaining ranks and
+ *   exits non-zero — a rank blocked in a collective whose peer died can never hang the host. The ranks' own spins
+ *   (barrier, unique-id hand-over) watch the same flag and the same deadline.
  */
+#include <signal.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,6 +44,7 @@ typedef struct Shared {
     unsigned char id[DRONE_GATHER_ID_BYTES];
     volatile int arrived[2]; /* sense-reversing barrier over the ranks */
     volatile int sense;
+    double deadline; /* CLOCK_MONOTONIC seconds after which every spin gives up (set by the parent before the fork) */
     double rank_seconds[64];
     uint32_t rank_crc[64]; /* CRC-32 of each rank's own slice of the outputs, chained over the launches */
 } Shared;
@@ -66,7 +72,8 @@ static double now_s(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-static void barrier(Shared* sh, int world, int* local_sense) {
+/* 0 = all ranks arrived; 1 = another rank failed or the deadline passed (the caller returns non-zero) */
+static int barrier(Shared* sh, int world, int* local_sense) {
     *local_sense = !*local_sense;
     const int slot = *local_sense;
     if (__sync_add_and_fetch(&sh->arrived[slot], 1) == world) {
@@ -74,12 +81,16 @@ static void barrier(Shared* sh, int world, int* local_sense) {
         __sync_synchronize();
         sh->sense = *local_sense;
     } else {
-        while (sh->sense != *local_sense && !sh->failed) usleep(50);
+        while (sh->sense != *local_sense) {
+            if (sh->failed || now_s() > sh->deadline) return 1;
+            usleep(50);
+        }
     }
+    return 0;
 }
 
 typedef struct Opts {
-    int gpus, total, steps, task, gather, rollout, crc, share;
+    int gpus, total, steps, task, gather, rollout, crc, share, timeout, die_rank;
     unsigned long long seed;
 } Opts;
 
@@ -122,8 +133,10 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
             __sync_synchronize();
             sh->id_ready = 1;
         } else {
-            while (!sh->id_ready && !sh->failed) usleep(100);
-            if (sh->failed) return 1;
+            while (!sh->id_ready) {
+                if (sh->failed || now_s() > sh->deadline) { fprintf(stderr, "rank %d: gave up waiting for the RCCL unique id\n", rank); return 1; }
+                usleep(100);
+            }
         }
         unsigned char id[DRONE_GATHER_ID_BYTES];
         memcpy(id, (const void*)sh->id, sizeof(id));
@@ -134,6 +147,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     }
 
     int sense = 0;
+    if (rank == o->die_rank) raise(SIGKILL); /* tests only: a rank that dies without saying so (OOM kill, segfault) */
     drone_vec_reset(v, o->seed);
     if (o->gather && drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
     uint32_t crc = 0, own = 0;
@@ -143,7 +157,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
         own = crc32_update(own, all_obs + off * od, sizeof(float) * (size_t)n * od);
     }
     const int launches = o->rollout > 0 ? (o->steps + o->rollout - 1) / o->rollout : o->steps;
-    barrier(sh, world, &sense);
+    if (barrier(sh, world, &sense)) { fprintf(stderr, "rank %d: start barrier abandoned (a rank failed or the time limit passed)\n", rank); return 1; }
     const double t0 = now_s();
     for (int t = 0; t < launches; t++) {
         if (o->rollout > 0) {
@@ -167,7 +181,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     sh->rank_crc[rank] = own;
     sh->rank_seconds[rank] = now_s() - t0;
     if (drone_vec_status(v)) { fprintf(stderr, "rank %d: %s\n", rank, drone_vec_status_message(v)); return 1; }
-    barrier(sh, world, &sense);
+    if (barrier(sh, world, &sense)) { fprintf(stderr, "rank %d: end barrier abandoned (a rank failed or the time limit passed)\n", rank); return 1; }
     if (rank == 0) {
         double el = 0;
         for (int r = 0; r < world; r++) el = sh->rank_seconds[r] > el ? sh->rank_seconds[r] : el;
@@ -187,7 +201,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
 }
 
 int main(int argc, char** argv) {
-    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 0ull};
+    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 300, -1, 0ull};
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--gpus")) o.gpus = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--envs")) o.total = atoi(argv[i + 1]);
@@ -197,9 +211,12 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--rollout")) o.rollout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--crc")) o.crc = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--share-devices")) o.share = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--timeout")) o.timeout = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--die-rank")) o.die_rank = atoi(argv[i + 1]); /* tests: that rank kills itself before the start barrier */
         else if (!strcmp(argv[i], "--seed")) o.seed = strtoull(argv[i + 1], NULL, 10);
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
+    if (o.timeout < 1) o.timeout = 1;
     if (o.gpus < 1 || o.gpus > 64 || o.total < o.gpus || o.steps < 1 || o.rollout < 0) { fprintf(stderr, "bad --gpus / --envs / --steps / --rollout\n"); return 2; }
     if (o.task < 0 || o.task > 3) { fprintf(stderr, "unknown task %d\n", o.task); return 2; }
     if (o.task == DRONE_TASK_SWARM && (o.total % (8 * o.gpus))) { fprintf(stderr, "swarm task: --envs must be a multiple of 8 x --gpus\n"); return 2; }
@@ -208,21 +225,50 @@ int main(int argc, char** argv) {
     Shared* sh = (Shared*)mmap(NULL, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (sh == MAP_FAILED) { perror("mmap"); return 1; }
     memset(sh, 0, sizeof(*sh));
+    sh->deadline = now_s() + (double)o.timeout;
     pid_t pids[64];
+    int started = 0;
     for (int r = 0; r < o.gpus; r++) {
         pids[r] = fork();
-        if (pids[r] < 0) { perror("fork"); sh->failed = 1; return 1; }
+        if (pids[r] < 0) { perror("fork"); sh->failed = 1; break; }
         if (pids[r] == 0) {
             const int rc = run_rank(&o, r, sh);
             if (rc) sh->failed = 1;
+            fflush(stdout);
             _exit(rc);
         }
+        started++;
     }
-    int rc = 0;
-    for (int r = 0; r < o.gpus; r++) {
+    /* Reap in ANY order, without blocking on one particular rank: a rank that dies by a signal never sets `failed`
+     * itself, and its peers may be blocked inside a collective (not in one of our spins) waiting for it. The first
+     * abnormal exit — or the wall-clock limit — kills the rest. */
+    int rc = started == o.gpus ? 0 : 1, alive = started;
+    while (alive > 0) {
         int st = 0;
-        waitpid(pids[r], &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st)) { rc = 1; sh->failed = 1; }
+        const pid_t p = waitpid(-1, &st, WNOHANG);
+        if (p > 0) {
+            alive--;
+            for (int r = 0; r < started; r++)
+                if (pids[r] == p) pids[r] = 0;
+            if (!WIFEXITED(st) || WEXITSTATUS(st)) {
+                if (!rc) fprintf(stderr, "drone_host_mp: a rank ended abnormally (%s %d): stopping the others\n",
+                                 WIFSIGNALED(st) ? "signal" : "status", WIFSIGNALED(st) ? WTERMSIG(st) : WEXITSTATUS(st));
+                rc = 1;
+            }
+        } else if (p < 0) {
+            break; /* no children left */
+        } else {
+            if (!rc && now_s() > sh->deadline + 2.0) { /* the ranks' own spins give up at the deadline; whoever is still here is stuck in a call */
+                fprintf(stderr, "drone_host_mp: time limit of %d s passed: stopping all ranks\n", o.timeout);
+                rc = 1;
+            }
+            usleep(2000);
+        }
+        if (rc && alive > 0) {
+            sh->failed = 1;
+            for (int r = 0; r < started; r++)
+                if (pids[r] > 0) kill(pids[r], SIGKILL);
+        }
     }
     return rc;
 }

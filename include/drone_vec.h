@@ -113,6 +113,20 @@ void drone_vec_step(DroneVec* v);
  * `actions` is neither read nor written. */
 void drone_vec_rollout(DroneVec* v, int horizon);
 
+/* K env steps in ONE launch, with the per-step outputs of every step (round 3). Exactly what
+ * `k_steps` calls of drone_vec_step would do — same trajectories, same auto-resets inside each step — except that the
+ * caller stages the K action rows up front and receives K steps' outputs in K-major blocks:
+ *   actions      [K][N][4] f32, or NULL: the SPEC.md §2 random policy is drawn in the kernel (as drone_vec_rollout does)
+ *   observations [K][N][drone_obs_dim(task)] f32, rewards [K][N] f32, terminals / truncations [K][N] u8
+ * all of the handle's buffer kind (device kind: 16-byte aligned observations / actions, written asynchronously on the
+ * stream; host kind: copied through device staging, returns after the copy). The handle's bound per-step buffers are
+ * neither read nor written. State stays in registers between the K steps: the dependent-launch boundary and the state
+ * planes' HBM traffic are paid once per K steps (hover: 102 + 176 / K bytes per env-step instead of 278), which is what
+ * small shards (one wave per SIMD, launch-boundary bound) need. Consumers: open-loop action segments, action repeat /
+ * frame skip, a device-side policy. With compact_done=1 every step's done-id list is kept: drone_vec_done_list_at. */
+void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
+                         unsigned char* terminals, unsigned char* truncations);
+
 void drone_vec_log(DroneVec* v, DroneLog* out);
 void drone_vec_close(DroneVec* v);
 
@@ -170,6 +184,10 @@ int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int c
  * ids. Returns 0 when the last path call was drone_vec_reset or
  * drone_vec_rollout (the fused rollout builds no list). */
 int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap);
+
+/* The same for step `k` (0 <= k < k_steps) of the last drone_vec_step_many; -1 if the last path call was not a
+ * step_many or k is out of range. */
+int drone_vec_done_list_at(DroneVec* v, int k, uint32_t* ids, int cap);
 
 /* ---- multi-GPU: the host-boundary exchange ----
  * Envs shard over GPUs with no collective on the env path (one process and one

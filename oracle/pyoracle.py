@@ -62,7 +62,7 @@ def lib():
             "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_bind_outputs", "drone_vec_done_list",
             "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error", "drone_device_count", "drone_vec_set_gstep", "drone_vec_enable_graph_capture", "drone_vec_status",
             "drone_vec_status_message", "drone_vec_clear_status", "drone_gather_unique_id", "drone_vec_gather_init",
-            "drone_vec_gather", "drone_vec_gather_close")]
+            "drone_vec_gather", "drone_vec_gather_close", "drone_vec_step_many", "drone_vec_done_list_at")]
         _fns = abi.bind(_lib, prefix_to="oracle_", names=names)
         _lib.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]
         _lib.oracle_hash32.restype = C.c_uint32
@@ -121,6 +121,25 @@ class OracleVec:
 
     def rollout(self, horizon):
         _fns["drone_vec_rollout"](self._h, horizon)
+
+    def step_many(self, k_steps, actions=None):
+        """What the product's drone_vec_step_many must reproduce: K plain c_step passes. ``actions`` [K][N][4], or None
+        for the random policy. Returns K-major (observations, rewards, terminals, truncations, done_ids per step)."""
+        n, od = self.num_envs, self.observations.shape[1]
+        obs = np.zeros((k_steps, n, od), np.float32)
+        rew = np.zeros((k_steps, n), np.float32)
+        term = np.zeros((k_steps, n), np.uint8)
+        trunc = np.zeros((k_steps, n), np.uint8)
+        done = []
+        for k in range(k_steps):
+            if actions is None:
+                self.fill_random_actions()
+            else:
+                self.actions[:] = actions[k]
+            self.step()
+            obs[k], rew[k], term[k], trunc[k] = self.observations, self.rewards, self.terminals, self.truncations
+            done.append(np.flatnonzero(self.terminals | self.truncations).astype(np.uint32))
+        return obs, rew, term, trunc, done
 
     def fill_random_actions(self, gstep=None, out=None):
         out = self.actions if out is None else out

@@ -28,8 +28,24 @@ def test_bench_line_has_the_contract_fields(hip):
     assert 0.0 < rf["frac"] < 1.0
     # value and the roofline come from the same launches: bytes/launch / launch time ~ value * bytes per env-step
     assert rf["achieved"] * 1e9 == pytest.approx(d["value"] * rf["algorithmic_bytes_per_env_step"], rel=0.2)
-    # round 2: the cache-free HBM fraction beside the headline one, and the config-5 roofline of the fused rollout
-    assert 0.0 < rf["frac_hbm_only"] < 1.0 and rf["hbm_only"]["envs"] >= 1 << 22
+    # the same kernel beyond the Infinity Cache (2^22 and 2^23 envs) beside the headline figure, and what `traffic` is
+    assert 0.0 < rf["frac_2pow22"] < 1.0 and rf["infinity_cache_assisted"] is True and rf["traffic_measured_in_this_run"] is False
+    pts = rf["beyond_infinity_cache"]
+    assert pts[str(1 << 22)]["envs"] == 1 << 22 and pts[str(1 << 22)]["frac"] == rf["frac_2pow22"]
+    assert str(1 << 23) in pts and ("frac" in pts[str(1 << 23)] or "skipped" in pts[str(1 << 23)])
+    # round 3: every other single-GPU BASELINE workload timed in the same run, each with its own bytes
+    cf = d["configs"]
+    assert set(cf) == {"configs[1]", "configs[2]/shard", "configs[3]"}
+    for name, envs, task, nbytes in (("configs[1]", 65536, "hover", 278), ("configs[2]/shard", 131072, "hover", 278), ("configs[3]", 262144, "waypoint", 310)):
+        c = cf[name]
+        assert "skipped" not in c, c
+        ps = c["per_step"]
+        assert c["envs"] == envs and c["task"] == task and ps["algorithmic_bytes_per_env_step"] == nbytes
+        assert ps["launch_us"] > 0 and 0.0 < ps["frac"] < 1.3  # 262 144 envs run from the Infinity Cache: above the HBM line by design
+        assert ps["achieved_GBps"] == pytest.approx(nbytes * envs / (ps["launch_us"] * 1e-6) / 1e9)
+    assert cf["configs[1]"]["fused_rollout"]["roofline"]["bound"] == "valu-f32"
+    sm = cf["configs[1]"]["step_many"]
+    assert sm["K32"]["algorithmic_bytes_per_env_step"] == pytest.approx(102 + 176 / 32) and sm["K32"]["us_per_env_step_launch_avg"] < ps_limit(cf)
     fr = d["fused_rollout"]["roofline"]
     assert fr["bound"] == "valu-f32" and fr["unit"] == "TFLOP/s" and fr["peak"] == 157.3
     assert fr["frac"] == pytest.approx(fr["achieved"] / fr["peak"]) and 0.0 < fr["frac"] < 1.0
@@ -40,22 +56,62 @@ def test_bench_line_has_the_contract_fields(hip):
     assert d["value"] > cb["value"]
 
 
+def ps_limit(cf):
+    """K steps per launch must beat one launch per step at 65 536 envs (that is what it is for)."""
+    return cf["configs[1]"]["per_step"]["launch_us"]
+
+
+def check_two_rank_line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    assert last.startswith("{"), "the JSON line must be the LAST line on stdout"
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 6 and d["warmup"] == 2
+    assert set(d["records"]) == {"no_gather", "gather_step", "gather_root_step", "gather_overlap", "rollout_no_gather", "rollout_gather",
+                                 "rollout_gather_root", "c_host_mp"}  # + rollout_gather_overlap on RCCL
+    ch = d["records"]["c_host_mp"]  # the plain-C multi-process host, run as a child with a timeout after the line was complete
+    assert ch["per_step"]["gpus"] == 2 and ch["per_step"]["envs"] == 131073 and ch["per_step"]["env_steps_per_s"] > 0
+    assert ch["rollout"]["horizon"] == 128 and ch["rollout"]["env_steps_per_s"] > 0
+    return d
+
+
+@pytest.mark.gpu
+def test_plain_python_launch_with_gpus_2_starts_its_own_ranks(hip):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts the ranks as a child process (before touching
+    HIP), relays rank 0's line last and returns the children's exit code."""
+    env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--total-envs", "131073"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    d = check_two_rank_line(r)
+    assert "rccl_ranks" in d and "warning" in d
+
+
+def test_self_launch_returns_the_childrens_failure_without_a_gpu():
+    """No GPU here: the ranks die on their first assert; the launcher must come back non-zero (and must not hang or print a line)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU")
+    env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total-envs", "1000"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.gpu
 def test_two_rank_launch_reports_the_metrics_configuration(hip):
     """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on a 1-GPU box: the oversubscribed gloo smoke path.
-    2^20-style strong split (here 2^17 total to keep it short), the four named records, `value` = configs[2]."""
+    2^20-style strong split (here 2^17 total to keep it short), the named records, `value` = configs[2]."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--total-envs", "131073"],
                        capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 6 and d["warmup"] == 2
-    assert set(d["records"]) == {"no_gather", "gather_step", "gather_overlap", "rollout_no_gather", "rollout_gather"}  # + rollout_gather_overlap on RCCL
+    d = check_two_rank_line(r)
     assert d["value_from"] == "gather_step" and d["value"] == d["records"]["gather_step"]["env_steps_per_s"]
     assert d["ms_per_step"] == d["records"]["gather_step"]["ms_per_step"]
     assert d["config"]["envs_per_gpu"] == 65537  # ragged split of 131073: rank 0 takes the extra env (shard_range)
-    for rec in d["records"].values():
-        assert rec["env_steps_per_s"] > 0 and rec["ms_per_step"] > 0
+    for name, rec in d["records"].items():
+        if name != "c_host_mp":
+            assert rec["env_steps_per_s"] > 0 and rec["ms_per_step"] > 0, (name, rec)
     assert d["records"]["rollout_gather"]["horizon"] == 128
     assert "rccl_ranks" in d and "warning" in d  # gloo smoke path on one GPU: flagged as not a measurement
