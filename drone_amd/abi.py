@@ -110,6 +110,7 @@ SYMBOLS = {
     "drone_vec_clear_status": (None, [_P]),
     "drone_gather_unique_id": (C.c_int, [_P]),
     "drone_vec_gather_init": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "drone_vec_gather_init_root": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "drone_vec_gather": (C.c_int, [_P]),
     "drone_vec_gather_close": (None, [_P]),
     "drone_vec_get_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),

@@ -276,16 +276,17 @@ class DroneVec:
         self._f["drone_vec_clear_status"](self._h)
 
     # -- host-boundary all-gather through the C-ABI (RCCL called from the library, not torch.distributed) --
-    def gather_init(self, unique_id, rank, world, all_observations, all_rewards, all_terminals, all_truncations, counts=None):
-        """``unique_id``: the DRONE_GATHER_ID_BYTES bytes rank 0 got from ``gather_unique_id()``."""
+    def gather_init(self, unique_id, rank, world, all_observations, all_rewards, all_terminals, all_truncations, counts=None, root=-1):
+        """``unique_id``: the DRONE_GATHER_ID_BYTES bytes rank 0 got from ``gather_unique_id()``. ``root`` = -1: all-gather
+        (every rank receives the batch); ``root`` >= 0: gather to that rank only — the other ranks pass ``None`` buffers."""
         idbuf = (C.c_ubyte * abi.GATHER_ID_BYTES).from_buffer_copy(bytes(unique_id))
         cnt = None
         if counts is not None:
             cnt = (C.c_int * world)(*[int(c) for c in counts])
         self._gathered = (all_observations, all_rewards, all_terminals, all_truncations)  # keep alive
-        self._check(self._f["drone_vec_gather_init"](self._h, C.cast(idbuf, C.c_void_p), int(rank), int(world),
-                                                      C.cast(cnt, C.c_void_p) if cnt is not None else None,
-                                                      _ptr(all_observations), _ptr(all_rewards), _ptr(all_terminals), _ptr(all_truncations)))
+        ptrs = [_ptr(b) if b is not None else None for b in self._gathered]
+        self._check(self._f["drone_vec_gather_init_root"](self._h, C.cast(idbuf, C.c_void_p), int(rank), int(world),
+                                                           C.cast(cnt, C.c_void_p) if cnt is not None else None, int(root), *ptrs))
 
     def gather(self):
         self._check(self._f["drone_vec_gather"](self._h))

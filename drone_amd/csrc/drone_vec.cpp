@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -296,38 +297,47 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// Loaded once per process, whichever thread gets there first (callers may drive one handle per host thread): the
+// table is filled under std::call_once and is read-only afterwards; a failed load is remembered with its reason.
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (r.lib) return &r;
-    if (tried) { set_err("librccl could not be loaded earlier in this process"); return nullptr; }
-    tried = true;
-    // DRONE_RCCL_LIB: another library with the same eight entry points (tests/rccl_stub: lets several ranks share one
-    // GPU, which RCCL itself refuses)
-    const char* alt = getenv("DRONE_RCCL_LIB");
-    const char* names[] = {alt && *alt ? alt : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.lib || (alt && *alt)) break;  // an explicit choice is not silently replaced
-    }
-    if (!r.lib) { set_err("dlopen(librccl.so.1) failed: %s", dlerror()); return nullptr; }
+    static std::once_flag once;
+    static char why[256] = "";
+    std::call_once(once, [] {
+        // DRONE_RCCL_LIB: another library with the same entry points (tests/rccl_stub: lets several ranks share one
+        // GPU, which RCCL itself refuses)
+        const char* alt = getenv("DRONE_RCCL_LIB");
+        const char* names[] = {alt && *alt ? alt : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* lib = nullptr;
+        for (const char* n : names) {
+            lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (lib || (alt && *alt)) break;  // an explicit choice is not silently replaced
+        }
+        if (!lib) { const char* e = dlerror(); snprintf(why, sizeof(why), "dlopen(librccl.so.1) failed: %s", e ? e : "?"); return; }
 #define RCCL_SYM(field, name)                                                        \
-    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name));               \
-    if (!r.field) { set_err("librccl has no symbol %s", name); dlclose(r.lib); r.lib = nullptr; return nullptr; }
-    RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
-    RCCL_SYM(CommInitRank, "ncclCommInitRank")
-    RCCL_SYM(CommDestroy, "ncclCommDestroy")
-    RCCL_SYM(AllGather, "ncclAllGather")
-    RCCL_SYM(Broadcast, "ncclBroadcast")
-    RCCL_SYM(GroupStart, "ncclGroupStart")
-    RCCL_SYM(GroupEnd, "ncclGroupEnd")
-    RCCL_SYM(GetErrorString, "ncclGetErrorString")
+        r.field = reinterpret_cast<decltype(r.field)>(dlsym(lib, name));             \
+        if (!r.field) { snprintf(why, sizeof(why), "librccl has no symbol %s", name); dlclose(lib); return; }
+        RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+        RCCL_SYM(CommInitRank, "ncclCommInitRank")
+        RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        RCCL_SYM(AllGather, "ncclAllGather")
+        RCCL_SYM(Broadcast, "ncclBroadcast")
+        RCCL_SYM(Send, "ncclSend")
+        RCCL_SYM(Recv, "ncclRecv")
+        RCCL_SYM(GroupStart, "ncclGroupStart")
+        RCCL_SYM(GroupEnd, "ncclGroupEnd")
+        RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RCCL_SYM
+        r.lib = lib;  // last: a non-null lib means every entry point is bound
+    });
+    if (!r.lib) { set_err("%s", why[0] ? why : "librccl could not be loaded"); return nullptr; }
     return &r;
 }
 
@@ -345,6 +355,7 @@ Rccl* rccl() {
 struct Gather {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    int root = -1;  // >= 0: gather to that rank only (ncclSend / ncclRecv); -1: all-gather, every rank receives the batch
     std::vector<size_t> counts, offsets;  // envs per rank, first global row of each rank
     size_t total = 0;
     bool equal = true;
@@ -1014,13 +1025,15 @@ int drone_gather_unique_id(unsigned char* id) {
     return 0;
 }
 
-int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts,
-                          float* all_observations, float* all_rewards, unsigned char* all_terminals, unsigned char* all_truncations) {
+int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts, int root,
+                               float* all_observations, float* all_rewards, unsigned char* all_terminals, unsigned char* all_truncations) {
     Entry in(v);
     if (!in) return -1;
     if (v->gather) { set_err("gather already initialised on this handle"); return -1; }
     if (!id || world < 1 || rank < 0 || rank >= world) { set_err("gather_init: bad id / rank %d / world %d", rank, world); return -1; }
-    if (!all_observations || !all_rewards || !all_terminals || !all_truncations) { set_err("gather_init: NULL global buffer"); return -1; }
+    if (root < -1 || root >= world) { set_err("gather_init: root %d outside [-1, %d)", root, world); return -1; }
+    const bool receives = root < 0 || root == rank;  // only a receiving rank needs the global buffers
+    if (receives && (!all_observations || !all_rewards || !all_terminals || !all_truncations)) { set_err("gather_init: NULL global buffer"); return -1; }
     Rccl* R = rccl();
     if (!R) return -1;
     Gather* g = new (std::nothrow) Gather();
@@ -1028,6 +1041,7 @@ int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int wo
     v->gather = g;
     g->rank = rank;
     g->world = world;
+    g->root = root;
     g->counts.resize(world);
     g->offsets.resize(world);
     for (int r = 0; r < world; r++) {
@@ -1044,26 +1058,28 @@ int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int wo
     if (v->host_buffers) {
         // the collective reads device memory: step into the device mirrors, gather into staging, copy the batch out
         if (v->zero_copy) leave_zero_copy(v);
-        g->own_staging = true;
-        g->h_obs = all_observations; g->h_rew = all_rewards; g->h_term = all_terminals; g->h_trunc = all_truncations;
-        // The local output buffers were pinned at init. Where they are slices of the global ones (the usual layout), a
-        // copy into the whole global buffer would then span pinned and pageable pages, which HIP rejects: drop the
-        // local pins (the mirror transport does not need them) and pin the global buffers whole instead, best effort.
-        for (int slot : {0, 2, 3, 4})
-            if (v->registered[slot]) { (void)hipHostUnregister(v->registered_ptr[slot]); v->registered[slot] = false; }
-        void* hosts[4] = {all_observations, all_rewards, all_terminals, all_truncations};
-        const size_t bytes[4] = {g->total * od * sizeof(float), g->total * sizeof(float), g->total, g->total};
-        for (int k = 0; k < 4; k++) {
-            g->h_registered[k] = hipHostRegister(hosts[k], bytes[k], hipHostRegisterDefault) == hipSuccess;
-            if (!g->h_registered[k]) (void)hipGetLastError();
-        }
+        if (receives) {
+            g->own_staging = true;
+            g->h_obs = all_observations; g->h_rew = all_rewards; g->h_term = all_terminals; g->h_trunc = all_truncations;
+            // The local output buffers were pinned at init. Where they are slices of the global ones (the usual layout), a
+            // copy into the whole global buffer would then span pinned and pageable pages, which HIP rejects: drop the
+            // local pins (the mirror transport does not need them) and pin the global buffers whole instead, best effort.
+            for (int slot : {0, 2, 3, 4})
+                if (v->registered[slot]) { (void)hipHostUnregister(v->registered_ptr[slot]); v->registered[slot] = false; }
+            void* hosts[4] = {all_observations, all_rewards, all_terminals, all_truncations};
+            const size_t bytes[4] = {g->total * od * sizeof(float), g->total * sizeof(float), g->total, g->total};
+            for (int k = 0; k < 4; k++) {
+                g->h_registered[k] = hipHostRegister(hosts[k], bytes[k], hipHostRegisterDefault) == hipSuccess;
+                if (!g->h_registered[k]) (void)hipGetLastError();
+            }
 #define G_TRY(expr) HIP_TRY(expr, { gather_destroy(v); return -1; })
-        G_TRY(hipMalloc((void**)&g->g_obs, g->total * od * sizeof(float)));
-        G_TRY(hipMalloc((void**)&g->g_rew, g->total * sizeof(float)));
-        G_TRY(hipMalloc((void**)&g->g_term, g->total));
-        G_TRY(hipMalloc((void**)&g->g_trunc, g->total));
+            G_TRY(hipMalloc((void**)&g->g_obs, g->total * od * sizeof(float)));
+            G_TRY(hipMalloc((void**)&g->g_rew, g->total * sizeof(float)));
+            G_TRY(hipMalloc((void**)&g->g_term, g->total));
+            G_TRY(hipMalloc((void**)&g->g_trunc, g->total));
 #undef G_TRY
-    } else {
+        }
+    } else if (receives) {
         if (reinterpret_cast<uintptr_t>(all_observations) & 15u) { set_err("gather_init: global observations must be 16-byte aligned"); gather_destroy(v); return -1; }
         g->g_obs = all_observations; g->g_rew = all_rewards; g->g_term = all_terminals; g->g_trunc = all_truncations;
     }
@@ -1071,6 +1087,11 @@ int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int wo
     memcpy(&u, id, sizeof(u));
     RCCL_TRY(R, R->CommInitRank(&g->comm, world, u, rank), { g->comm = nullptr; gather_destroy(v); return -1; });
     return 0;
+}
+
+int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts,
+                          float* all_observations, float* all_rewards, unsigned char* all_terminals, unsigned char* all_truncations) {
+    return drone_vec_gather_init_root(v, id, rank, world, counts, -1, all_observations, all_rewards, all_terminals, all_truncations);
 }
 
 int drone_vec_gather(DroneVec* v) {
@@ -1089,9 +1110,35 @@ int drone_vec_gather(DroneVec* v) {
     const unsigned char* s_trunc = v->dv.trunc;
     // one grouped launch for the four buffers; a send buffer that already is this rank's slice of the
     // global buffer makes the collective in-place
+    if (g->root >= 0 && g->rank == g->root) {
+        // the root's own rows need no link: a device copy, unless the kernels already write them in place
+        const size_t o = g->offsets[g->rank];
+        if (s_obs != g->g_obs + o * od) HIP_TRY(hipMemcpyAsync(g->g_obs + o * od, s_obs, n * od * sizeof(float), hipMemcpyDeviceToDevice, v->stream), return -1);
+        if (s_rew != g->g_rew + o) HIP_TRY(hipMemcpyAsync(g->g_rew + o, s_rew, n * sizeof(float), hipMemcpyDeviceToDevice, v->stream), return -1);
+        if (s_term != g->g_term + o) HIP_TRY(hipMemcpyAsync(g->g_term + o, s_term, n, hipMemcpyDeviceToDevice, v->stream), return -1);
+        if (s_trunc != g->g_trunc + o) HIP_TRY(hipMemcpyAsync(g->g_trunc + o, s_trunc, n, hipMemcpyDeviceToDevice, v->stream), return -1);
+    }
     RCCL_TRY(R, R->GroupStart(), return -1);
     bool ok = true;
-    if (g->equal) {
+    if (g->root >= 0) {
+        // gather to ONE rank: every other rank sends its rows once; the root receives each rank's rows into their place.
+        // Against the all-gather the 7 non-root GPUs of a node stop receiving (and writing to HBM) 7/8 of the batch each.
+        if (g->rank != g->root) {
+            ok = ok && R->Send(s_obs, n * od, ncclFloat, g->root, g->comm, v->stream) == ncclSuccess;
+            ok = ok && R->Send(s_rew, n, ncclFloat, g->root, g->comm, v->stream) == ncclSuccess;
+            ok = ok && R->Send(s_term, n, ncclUint8, g->root, g->comm, v->stream) == ncclSuccess;
+            ok = ok && R->Send(s_trunc, n, ncclUint8, g->root, g->comm, v->stream) == ncclSuccess;
+        } else {
+            for (int r = 0; r < g->world && ok; r++) {
+                if (r == g->rank) continue;
+                const size_t c = g->counts[r], o = g->offsets[r];
+                ok = ok && R->Recv(g->g_obs + o * od, c * od, ncclFloat, r, g->comm, v->stream) == ncclSuccess;
+                ok = ok && R->Recv(g->g_rew + o, c, ncclFloat, r, g->comm, v->stream) == ncclSuccess;
+                ok = ok && R->Recv(g->g_term + o, c, ncclUint8, r, g->comm, v->stream) == ncclSuccess;
+                ok = ok && R->Recv(g->g_trunc + o, c, ncclUint8, r, g->comm, v->stream) == ncclSuccess;
+            }
+        }
+    } else if (g->equal) {
         ok = ok && R->AllGather(s_obs, g->g_obs, n * od, ncclFloat, g->comm, v->stream) == ncclSuccess;
         ok = ok && R->AllGather(s_rew, g->g_rew, n, ncclFloat, g->comm, v->stream) == ncclSuccess;
         ok = ok && R->AllGather(s_term, g->g_term, n, ncclUint8, g->comm, v->stream) == ncclSuccess;
@@ -1108,7 +1155,7 @@ int drone_vec_gather(DroneVec* v) {
     }
     RCCL_TRY(R, R->GroupEnd(), return -1);
     if (!ok) { set_err("an RCCL collective of drone_vec_gather failed to enqueue"); return -1; }
-    if (v->host_buffers) {
+    if (v->host_buffers && g->own_staging) {  // receiving ranks only: the batch goes out to the caller's host buffers
         HIP_TRY(hipMemcpyAsync(g->h_obs, g->g_obs, g->total * od * sizeof(float), hipMemcpyDeviceToHost, v->stream), return -1);
         HIP_TRY(hipMemcpyAsync(g->h_rew, g->g_rew, g->total * sizeof(float), hipMemcpyDeviceToHost, v->stream), return -1);
         HIP_TRY(hipMemcpyAsync(g->h_term, g->g_term, g->total, hipMemcpyDeviceToHost, v->stream), return -1);

@@ -6,7 +6,9 @@ owns a contiguous range of global env ids and passes its start as
 trajectory of env e does not depend on the shard it lands in). The only
 exchange is at the host boundary: an all-gather of observations / rewards /
 flags for a consumer that wants the whole batch on every rank (RCCL over xGMI
-when the tensors are in HBM; the same code runs on gloo with CPU tensors).
+when the tensors are in HBM; the same code runs on gloo with CPU tensors), or
+— ``RootGather`` — a gather to ONE rank for a single consumer process: every
+other rank sends its rows once and receives nothing.
 """
 import contextlib
 
@@ -94,6 +96,52 @@ class BoundaryGather:
             return self.obs, self.rew, self.term, self.trunc
         keep = self._keep
         return self.obs[keep], self.rew[keep], self.term[keep], self.trunc[keep]
+
+
+class RootGather:
+    """Pre-allocated gather of the per-step outputs of every shard TO ONE RANK (the north-star's "RCCL gather").
+
+    Point-to-point: every non-root rank posts one send per buffer, the root one receive per (rank, buffer) straight
+    into that rank's rows of the global buffers — ragged shards need no padding — all batched into one launch
+    (``batch_isend_irecv`` = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on RCCL). Against the all-gather,
+    the N-1 other GPUs stop receiving and writing (N-1)/N of the batch each; the root's inbound traffic is the same.
+    ``__call__`` returns the global tensors on the root, ``None`` elsewhere.
+    """
+
+    def __init__(self, total_envs, obs_dim, device, root=0, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.root = int(root)
+        if not 0 <= self.root < self.world:
+            raise ValueError(f"root {root} outside the group of {self.world}")
+        self.total = int(total_envs)
+        self.counts = shard_counts(self.total, self.world)
+        self.offsets = [shard_range(self.total, r, self.world)[0] for r in range(self.world)]
+        self._peer = [r if group is None else dist.get_global_rank(group, r) for r in range(self.world)]
+        self.obs = self.rew = self.term = self.trunc = None
+        if self.rank == self.root:
+            self.obs = torch.empty((self.total, obs_dim), dtype=torch.float32, device=device)
+            self.rew = torch.empty(self.total, dtype=torch.float32, device=device)
+            self.term = torch.empty(self.total, dtype=torch.uint8, device=device)
+            self.trunc = torch.empty(self.total, dtype=torch.uint8, device=device)
+
+    def __call__(self, obs, rew, term, trunc):
+        srcs = (obs, rew, term, trunc)
+        if self.rank != self.root:
+            ops = [dist.P2POp(dist.isend, t.contiguous(), self._peer[self.root], self.group) for t in srcs]
+        else:
+            dsts = (self.obs, self.rew, self.term, self.trunc)
+            mine = slice(self.offsets[self.rank], self.offsets[self.rank] + self.counts[self.rank])
+            for d, t in zip(dsts, srcs):
+                if d[mine].data_ptr() != t.data_ptr():  # in place when the env already writes into its rows
+                    d[mine].copy_(t)
+            ops = [dist.P2POp(dist.irecv, d[self.offsets[r]:self.offsets[r] + self.counts[r]], self._peer[r], self.group)
+                   for r in range(self.world) if r != self.rank for d in dsts]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return (self.obs, self.rew, self.term, self.trunc) if self.rank == self.root else None
 
 
 class PipelinedGather:

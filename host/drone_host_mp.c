@@ -8,7 +8,7 @@
  * here: both stay behind the C-ABI.
  *
  *   drone_host_mp [--gpus G] [--envs TOTAL] [--steps K] [--task 0..3] [--seed S]
- *                 [--gather 0|1] [--rollout T] [--crc 1] [--share-devices 1] [--timeout SECONDS]
+ *                 [--gather 0|1] [--root R] [--rollout T] [--crc 1] [--share-devices 1] [--timeout SECONDS]
  *
  * Rank r takes envs [offset_r, offset_r + count_r) (the first TOTAL % G ranks get
  * one more) on device r. The RCCL unique id is made by rank 0 AFTER the fork and
@@ -17,6 +17,8 @@
  * batch in host memory (its local buffers are its slice of the global ones).
  * Rank 0 prints one JSON line; with --crc 1 the CRC-32 chained over every step's
  * gathered batch, which tests/test_c_host.py compares with the CPU oracle's.
+ * --root R (default -1): -1 = all-gather, every rank ends up with the whole batch; R >= 0 = gather to rank R only
+ *   (ncclSend / ncclRecv): the batch lands in rank R's host buffers, the printed CRC is rank R's.
  * --rollout T: fused T-step rollouts with the gather once per horizon (configs[4]).
  * --share-devices 1: rank r uses device r %% (visible devices) — lets the fork / shard / barrier logic run with several
  *   ranks on a one-GPU box (without --gather: RCCL refuses two ranks on one device); every rank's CRC over ITS OWN
@@ -47,6 +49,7 @@ typedef struct Shared {
     double deadline; /* CLOCK_MONOTONIC seconds after which every spin gives up (set by the parent before the fork) */
     double rank_seconds[64];
     uint32_t rank_crc[64]; /* CRC-32 of each rank's own slice of the outputs, chained over the launches */
+    uint32_t batch_crc[64]; /* CRC-32 of the whole gathered batch as each rank sees it (meaningful on receiving ranks) */
 } Shared;
 
 static uint32_t crc32_update(uint32_t crc, const void* buf, size_t len) {
@@ -90,7 +93,7 @@ static int barrier(Shared* sh, int world, int* local_sense) {
 }
 
 typedef struct Opts {
-    int gpus, total, steps, task, gather, rollout, crc, share, timeout, die_rank;
+    int gpus, total, steps, task, gather, rollout, crc, share, timeout, die_rank, root;
     unsigned long long seed;
 } Opts;
 
@@ -140,7 +143,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
         }
         unsigned char id[DRONE_GATHER_ID_BYTES];
         memcpy(id, (const void*)sh->id, sizeof(id));
-        if (drone_vec_gather_init(v, id, rank, world, counts, all_obs, all_rew, all_term, all_trunc) != 0) {
+        if (drone_vec_gather_init_root(v, id, rank, world, counts, o->root, all_obs, all_rew, all_term, all_trunc) != 0) {
             fprintf(stderr, "rank %d: drone_vec_gather_init failed: %s\n", rank, drone_last_error());
             return 1;
         }
@@ -179,6 +182,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
         }
     }
     sh->rank_crc[rank] = own;
+    sh->batch_crc[rank] = crc;
     sh->rank_seconds[rank] = now_s() - t0;
     if (drone_vec_status(v)) { fprintf(stderr, "rank %d: %s\n", rank, drone_vec_status_message(v)); return 1; }
     if (barrier(sh, world, &sense)) { fprintf(stderr, "rank %d: end barrier abandoned (a rank failed or the time limit passed)\n", rank); return 1; }
@@ -186,10 +190,10 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
         double el = 0;
         for (int r = 0; r < world; r++) el = sh->rank_seconds[r] > el ? sh->rank_seconds[r] : el;
         const double env_steps = (double)o->total * (o->rollout > 0 ? (double)o->rollout : 1.0) * launches;
-        printf("{\"mode\": \"%s%s\", \"gpus\": %d, \"task\": %d, \"envs\": %d, \"launches\": %d, \"horizon\": %d, \"env_steps_per_s\": %.4g, "
+        printf("{\"mode\": \"%s%s\", \"gpus\": %d, \"root\": %d, \"task\": %d, \"envs\": %d, \"launches\": %d, \"horizon\": %d, \"env_steps_per_s\": %.4g, "
                "\"ms_per_launch\": %.4f, \"crc32\": %u, \"rank_crc32\": [",
-               o->rollout > 0 ? "fused rollout" : "per-step", o->gather ? " + RCCL all-gather to every rank's host batch" : " (no gather)", world, o->task,
-               o->total, launches, o->rollout, env_steps / el, el * 1e3 / launches, crc);
+               o->rollout > 0 ? "fused rollout" : "per-step", !o->gather ? " (no gather)" : o->root >= 0 ? " + RCCL gather to one rank's host batch" : " + RCCL all-gather to every rank's host batch", world, o->gather ? o->root : -1, o->task,
+               o->total, launches, o->rollout, env_steps / el, el * 1e3 / launches, sh->batch_crc[o->root >= 0 ? o->root : 0]);
         for (int r = 0; r < world; r++) printf("%s%u", r ? ", " : "", sh->rank_crc[r]);
         printf("]}\n");
         fflush(stdout);
@@ -201,7 +205,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
 }
 
 int main(int argc, char** argv) {
-    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 300, -1, 0ull};
+    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 300, -1, -1, 0ull};
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--gpus")) o.gpus = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--envs")) o.total = atoi(argv[i + 1]);
@@ -211,6 +215,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--rollout")) o.rollout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--crc")) o.crc = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--share-devices")) o.share = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--root")) o.root = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--timeout")) o.timeout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--die-rank")) o.die_rank = atoi(argv[i + 1]); /* tests: that rank kills itself before the start barrier */
         else if (!strcmp(argv[i], "--seed")) o.seed = strtoull(argv[i + 1], NULL, 10);
@@ -218,6 +223,7 @@ int main(int argc, char** argv) {
     }
     if (o.timeout < 1) o.timeout = 1;
     if (o.gpus < 1 || o.gpus > 64 || o.total < o.gpus || o.steps < 1 || o.rollout < 0) { fprintf(stderr, "bad --gpus / --envs / --steps / --rollout\n"); return 2; }
+    if (o.root < -1 || o.root >= o.gpus) { fprintf(stderr, "--root must be -1 or a rank\n"); return 2; }
     if (o.task < 0 || o.task > 3) { fprintf(stderr, "unknown task %d\n", o.task); return 2; }
     if (o.task == DRONE_TASK_SWARM && (o.total % (8 * o.gpus))) { fprintf(stderr, "swarm task: --envs must be a multiple of 8 x --gpus\n"); return 2; }
 

@@ -212,6 +212,14 @@ int drone_gather_unique_id(unsigned char* id);
 int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts,
                           float* all_observations, float* all_rewards,
                           unsigned char* all_terminals, unsigned char* all_truncations);
+/* The same bootstrap with a choice of exchange (round 3). root = -1: the all-gather above. root in [0, world): a
+ * gather TO THAT RANK only — every other rank ncclSends its rows once, the root ncclRecvs each rank's rows into their
+ * place in its global buffers (one grouped launch); non-root ranks receive nothing and may pass NULL for the four
+ * all_* pointers. For one consumer process (a trainer on rank 0) this is the north-star's "RCCL gather": against the
+ * all-gather, the other 7 GPUs of a node stop receiving and writing 7/8 of the batch each. */
+int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts, int root,
+                               float* all_observations, float* all_rewards,
+                               unsigned char* all_terminals, unsigned char* all_truncations);
 int drone_vec_gather(DroneVec* v);
 void drone_vec_gather_close(DroneVec* v);
 

@@ -38,6 +38,55 @@ def _worker(rank, world, port, total, steps, task, q):
     dist.destroy_process_group()
 
 
+def _root_worker(rank, world, port, total, steps, task, root, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drone_amd import abi
+    from drone_amd.dist import RootGather, shard_range
+    from oracle import pyoracle
+
+    off, cnt = shard_range(total, rank, world)
+    v = pyoracle.OracleVec(cnt, seed=5, cfg=pyoracle.default_config(task, env_offset=off, horizon=30))
+    v.reset(5)
+    g = RootGather(total, abi.OBS_DIM, torch.device("cpu"), root=root)
+    assert (g.obs is not None) == (rank == root)  # only the root holds global buffers
+    out = None
+    for _ in range(steps):
+        v.fill_random_actions()
+        v.step()
+        out = g(torch.from_numpy(v.observations), torch.from_numpy(v.rewards), torch.from_numpy(v.terminals), torch.from_numpy(v.truncations))
+        assert (out is not None) == (rank == root)
+    if rank == root:
+        q.put(tuple(t.numpy().copy() for t in out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,root", [(2, 256, 0), (2, 257, 1), (3, 1000, 2)])
+def test_gather_to_root_equals_single_vec(oracle, world, total, root):
+    """RootGather on gloo: equal and ragged shards, first / last rank as the root; the root's batch is one oracle run's."""
+    steps, task = 40, 1
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29700 + (os.getpid() % 2000) + total % 11 + root
+    procs = [ctx.Process(target=_root_worker, args=(r, world, port, total, steps, task, root, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    obs, rew, term, trunc = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    whole = oracle.OracleVec(total, seed=5, cfg=oracle.default_config(task, horizon=30))
+    whole.reset(5)
+    for _ in range(steps):
+        whole.fill_random_actions()
+        whole.step()
+    assert obs.tobytes() == whole.observations.tobytes() and rew.tobytes() == whole.rewards.tobytes()
+    assert term.tobytes() == whole.terminals.tobytes() and trunc.tobytes() == whole.truncations.tobytes()
+
+
 class _OracleAsVec:
     """Gives the CPU oracle the bind_outputs()/step() surface PipelinedGather drives."""
 

@@ -25,19 +25,22 @@ def stub(tmp_path_factory, hip):
     return out
 
 
-@pytest.mark.parametrize("ranks,envs,task,rollout", [(2, 6000, 0, 0), (3, 10001, 1, 0), (2, 4096, 3, 16), (3, 6144, 2, 0)])
-def test_c_host_mp_gathers_across_ranks(stub, oracle, ranks, envs, task, rollout):
+@pytest.mark.parametrize("ranks,envs,task,rollout,root", [(2, 6000, 0, 0, -1), (3, 10001, 1, 0, -1), (2, 4096, 3, 16, -1), (3, 6144, 2, 0, -1),
+                                                          (2, 6000, 0, 0, 0), (3, 10001, 1, 0, 2), (3, 6144, 2, 16, 1), (2, 4097, 3, 0, 1)])
+def test_c_host_mp_gathers_across_ranks(stub, oracle, ranks, envs, task, rollout, root):
     """host/drone_host_mp with several ranks: fork before HIP, id through the shared page, gather_init with the ranks'
     counts (equal -> all-gather, ragged -> one broadcast per rank), the gathered batch of every launch CRC'd on rank 0
-    against ONE oracle run over all envs — so every rank's slice landed at its global offset."""
+    against ONE oracle run over all envs — so every rank's slice landed at its global offset. root >= 0: the gather to
+    one rank (ncclSend / ncclRecv in one group), first and last rank, equal and ragged counts; the CRC is the root's."""
     steps, seed = 48, 31
     cmd = [EXE_MP, "--gpus", str(ranks), "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed),
-           "--crc", "1", "--gather", "1", "--share-devices", "1"]
+           "--crc", "1", "--gather", "1", "--share-devices", "1", "--root", str(root)]
     if rollout:
         cmd += ["--rollout", str(rollout)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, DRONE_RCCL_LIB=stub))
     assert r.returncode == 0, r.stderr + r.stdout
     got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert got["root"] == root
     o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=4)
     o.reset(seed)
     crc = zlib.crc32(o.observations.tobytes())
@@ -61,14 +64,22 @@ from drone_amd import abi, binding
 from drone_amd.dist import shard_range
 rank, world, total, task, steps, seed = (int(x) for x in sys.argv[1:7])
 idfile = sys.argv[7]
+root, inplace = int(sys.argv[9]), int(sys.argv[10])
+receives = root < 0 or root == rank
 dev = torch.device("cuda:0")
 off, cnt = shard_range(total, rank, world)
 od = abi.obs_dim(task)
-g_obs = torch.zeros((total, od), dtype=torch.float32, device=dev); g_rew = torch.zeros(total, dtype=torch.float32, device=dev)
-g_term = torch.zeros(total, dtype=torch.uint8, device=dev); g_trunc = torch.zeros(total, dtype=torch.uint8, device=dev)
+rows = total if receives else cnt  # a rank that receives nothing needs no global buffers
+g_obs = torch.zeros((rows, od), dtype=torch.float32, device=dev); g_rew = torch.zeros(rows, dtype=torch.float32, device=dev)
+g_term = torch.zeros(rows, dtype=torch.uint8, device=dev); g_trunc = torch.zeros(rows, dtype=torch.uint8, device=dev)
 act = torch.zeros((cnt, 4), dtype=torch.float32, device=dev)
-sl = slice(off, off + cnt)
-v = binding.DroneVec(cnt, seed=seed, cfg=binding.default_config(task, env_offset=off, horizon=20), buffers=(g_obs[sl], act, g_rew[sl], g_term[sl], g_trunc[sl]))
+sl = slice(off, off + cnt) if receives else slice(0, cnt)
+if inplace or not receives:
+    local = (g_obs[sl], act, g_rew[sl], g_term[sl], g_trunc[sl])
+else:  # the root writes into buffers of its own: its rows reach the global buffers by a device copy inside drone_vec_gather
+    local = (torch.zeros((cnt, od), dtype=torch.float32, device=dev), act, torch.zeros(cnt, dtype=torch.float32, device=dev),
+             torch.zeros(cnt, dtype=torch.uint8, device=dev), torch.zeros(cnt, dtype=torch.uint8, device=dev))
+v = binding.DroneVec(cnt, seed=seed, cfg=binding.default_config(task, env_offset=off, horizon=20), buffers=local)
 if rank == 0:
     uid = binding.gather_unique_id()
     with open(idfile + ".tmp", "wb") as fh: fh.write(uid)
@@ -77,7 +88,8 @@ else:
     import time
     while not os.path.exists(idfile): time.sleep(0.01)
     uid = open(idfile, "rb").read()
-v.gather_init(uid, rank, world, g_obs, g_rew, g_term, g_trunc, counts=[shard_range(total, r, world)[1] for r in range(world)])
+glob = (g_obs, g_rew, g_term, g_trunc) if receives else (None, None, None, None)
+v.gather_init(uid, rank, world, *glob, counts=[shard_range(total, r, world)[1] for r in range(world)], root=root)
 v.reset(seed); v.gather()
 for t in range(steps):
     v.fill_random_actions(); v.step(); v.gather()
@@ -87,17 +99,19 @@ v.gather_close(); v.close()
 """
 
 
-@pytest.mark.parametrize("world,total,task", [(2, 8192, 0), (3, 7001, 1)])
-def test_in_place_device_gather_across_ranks(stub, oracle, tmp_path, world, total, task):
+@pytest.mark.parametrize("world,total,task,root,inplace", [(2, 8192, 0, -1, 1), (3, 7001, 1, -1, 1), (2, 8192, 0, 0, 1), (3, 7001, 1, 2, 1), (3, 7001, 3, 1, 0)])
+def test_in_place_device_gather_across_ranks(stub, oracle, tmp_path, world, total, task, root, inplace):
     """Device buffers: every rank's output buffers ARE its slice of its global buffers (the in-place form bench.py's
-    C-ABI record uses); after each gather every rank holds the whole batch, identical to one oracle run."""
+    C-ABI record uses); after each gather every receiving rank holds the whole batch, identical to one oracle run.
+    root >= 0: only that rank receives (the others pass no global buffers); inplace = 0: the root's own rows are
+    copied into place on the device."""
     steps, seed = 30, 17
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
     idfile = str(tmp_path / "uid")
     outs = [str(tmp_path / f"out{r}.npz") for r in range(world)]
     env = dict(os.environ, DRONE_RCCL_LIB=stub)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(total), str(task), str(steps), str(seed), idfile, outs[r]],
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(total), str(task), str(steps), str(seed), idfile, outs[r], str(root), str(inplace)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     for p in procs:
         so, se = p.communicate(timeout=600)
@@ -108,6 +122,8 @@ def test_in_place_device_gather_across_ranks(stub, oracle, tmp_path, world, tota
         o.fill_random_actions()
         o.step()
     for r in range(world):
+        if root >= 0 and r != root:
+            continue
         g = np.load(outs[r])
         assert g["obs"].tobytes() == o.observations.tobytes(), f"rank {r}: observations"
         assert g["rew"].tobytes() == o.rewards.tobytes(), f"rank {r}: rewards"

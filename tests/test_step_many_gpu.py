@@ -54,13 +54,13 @@ def check_call(o, h, bufs, K, what, policy=False, lists=False):
 @pytest.mark.parametrize("device", [None, "cuda:0"])
 def test_step_many_equals_k_plain_steps(oracle, hip, task, device):
     n = 1000 if task != 2 else 1000 // 8 * 8  # ragged: 3 full workgroups + a partial one
-    o, h = pair(oracle, hip, n, 17 + task, task, device=device, horizon=50)
+    o, h = pair(oracle, hip, n, 17 + task, task, device=device, horizon=20)  # 49 steps: every env is truncated and reset twice
     ends = 0
     for K in (1, 2, 7, 32, 7):
         bufs = h.alloc_step_many(K)
         ends += check_call(o, h, bufs, K, f"task {task} K={K}")
         assert_state_equal(o.get_state(), h.get_state(), f"task {task} state after K={K}")
-    assert ends > n // 2  # episode ends (and the resets inside the K steps) were exercised
+    assert ends >= 2 * n  # episode ends (and the resets inside the K steps) were exercised
     # and plain stepping continues from where step_many left off
     o.fill_random_actions()
     if device is None:
