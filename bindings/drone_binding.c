@@ -34,6 +34,8 @@ typedef struct Handle {
     int n_views;
     PyObject* keep[5];  /* device mode: strong references to the tensors */
     int n_keep;
+    size_t n, obs_dim;  /* envs, floats per observation row */
+    int device_kind;    /* 1: buffers are device tensors */
 } Handle;
 
 static void handle_free(Handle* h) {
@@ -118,6 +120,49 @@ static int device_pointer(PyObject* o, void** out) {
     return 1;
 }
 
+/* Host buffers must hold what the env writes through them: f32 items for observations / actions / rewards, one-byte
+ * items for the flags (a float64 or int32 array of sufficient byte length would otherwise be written through a wrong
+ * layout silently). `want_float`: 1 = 4-byte float items, 0 = 1-byte items. The view was requested with PyBUF_FORMAT. */
+static int check_host_format(const Py_buffer* view, int want_float, const char* name) {
+    const char* f = view->format ? view->format : "B";
+    while (*f == '@' || *f == '=' || *f == '<') f++; /* native / little-endian prefixes */
+    const int ok = want_float ? (view->itemsize == 4 && f[0] == 'f' && f[1] == 0)
+                              : (view->itemsize == 1 && (f[0] == 'B' || f[0] == 'b' || f[0] == '?' || f[0] == 'c') && f[1] == 0);
+    if (!ok) {
+        PyErr_Format(PyExc_TypeError, "%s: expected %s items, got format '%s' (itemsize %zd)", name, want_float ? "float32" : "uint8 / bool", view->format ? view->format : "B", view->itemsize);
+        return -1;
+    }
+    return 0;
+}
+
+/* Device tensors: dtype by element_size() + is_floating_point(), layout by is_contiguous(), size by numel(). */
+static int check_device_tensor(PyObject* t, int want_float, size_t need_bytes, const char* name) {
+    PyObject* ne = PyObject_CallMethod(t, "numel", NULL);
+    PyObject* es = ne ? PyObject_CallMethod(t, "element_size", NULL) : NULL;
+    if (!ne || !es) { Py_XDECREF(ne); Py_XDECREF(es); return -1; }
+    const size_t esz = PyLong_AsSize_t(es), have = PyLong_AsSize_t(ne) * esz;
+    Py_DECREF(ne);
+    Py_DECREF(es);
+    if (PyErr_Occurred()) return -1;
+    if (have < need_bytes) { PyErr_Format(PyExc_ValueError, "%s holds %zu bytes, %zu needed", name, have, need_bytes); return -1; }
+    if (esz != (want_float ? 4u : 1u)) { PyErr_Format(PyExc_TypeError, "%s: expected %s elements, got %zu-byte ones", name, want_float ? "float32" : "uint8 / bool", esz); return -1; }
+    if (PyObject_HasAttrString(t, "is_floating_point")) {
+        PyObject* fp = PyObject_CallMethod(t, "is_floating_point", NULL);
+        if (!fp) return -1;
+        const int is_fp = PyObject_IsTrue(fp);
+        Py_DECREF(fp);
+        if (is_fp != (want_float ? 1 : 0)) { PyErr_Format(PyExc_TypeError, "%s: expected a %s tensor", name, want_float ? "float32" : "uint8 / bool"); return -1; }
+    }
+    if (PyObject_HasAttrString(t, "is_contiguous")) {
+        PyObject* c = PyObject_CallMethod(t, "is_contiguous", NULL);
+        if (!c) return -1;
+        const int contiguous = PyObject_IsTrue(c);
+        Py_DECREF(c);
+        if (!contiguous) { PyErr_Format(PyExc_ValueError, "%s must be contiguous", name); return -1; }
+    }
+    return 0;
+}
+
 /* vec_init(observations, actions, rewards, terminals, truncations, num_envs, seed, **env_kwargs) -> handle */
 static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
     (void)self;
@@ -157,20 +202,14 @@ static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
         }
         kind = isdev;
         if (isdev) {
-            /* size check through numel() * element_size() when the object offers them (torch tensors do) */
-            PyObject* ne = PyObject_CallMethod(bufs[i], "numel", NULL);
-            PyObject* es = ne ? PyObject_CallMethod(bufs[i], "element_size", NULL) : NULL;
-            if (!ne || !es) { Py_XDECREF(ne); Py_XDECREF(es); handle_free(h); return NULL; }
-            const size_t have = (size_t)PyLong_AsSize_t(ne) * (size_t)PyLong_AsSize_t(es);
-            Py_DECREF(ne);
-            Py_DECREF(es);
-            if (have < need[i]) { PyErr_Format(PyExc_ValueError, "vec_init: %s holds %zu bytes, %zu needed", names[i], have, need[i]); handle_free(h); return NULL; }
+            if (check_device_tensor(bufs[i], i < 3, need[i], names[i]) < 0) { handle_free(h); return NULL; }
             Py_INCREF(bufs[i]);
             h->keep[h->n_keep++] = bufs[i];
             ptr[i] = d;
         } else {
-            if (PyObject_GetBuffer(bufs[i], &h->views[h->n_views], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) { handle_free(h); return NULL; }
+            if (PyObject_GetBuffer(bufs[i], &h->views[h->n_views], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) { handle_free(h); return NULL; }
             h->n_views++;
+            if (check_host_format(&h->views[i], i < 3, names[i]) < 0) { handle_free(h); return NULL; }
             if ((size_t)h->views[i].len < need[i]) {
                 PyErr_Format(PyExc_ValueError, "vec_init: %s holds %zd bytes, %zu needed", names[i], h->views[i].len, need[i]);
                 handle_free(h);
@@ -180,6 +219,9 @@ static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
         }
     }
     cfg.buffer_kind = kind ? DRONE_BUFFERS_DEVICE : DRONE_BUFFERS_HOST;
+    h->n = (size_t)num_envs;
+    h->obs_dim = od;
+    h->device_kind = kind;
     Py_BEGIN_ALLOW_THREADS
     h->v = drone_vec_init((float*)ptr[0], (float*)ptr[1], (float*)ptr[2], (unsigned char*)ptr[3], (unsigned char*)ptr[4], num_envs, seed, &cfg);
     Py_END_ALLOW_THREADS
@@ -233,6 +275,67 @@ static PyObject* vec_rollout(PyObject* self, PyObject* args) {
     Py_END_ALLOW_THREADS
     if (raise_if_failed(h) < 0) return NULL;
     Py_RETURN_NONE;
+}
+
+/* vec_step_many(handle, k_steps, actions | None, observations, rewards, terminals, truncations): K env steps in one
+ * launch with every step's outputs, into K-major blocks of the env's buffer kind ([K][N][4] in, [K][N][O] / [K][N] out);
+ * actions = None draws the SPEC.md random policy in the kernel. */
+static PyObject* vec_step_many(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject *cap, *blk[5];
+    int k_steps;
+    if (!PyArg_ParseTuple(args, "OiOOOOO", &cap, &k_steps, &blk[0], &blk[1], &blk[2], &blk[3], &blk[4])) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    if (k_steps < 1) { PyErr_SetString(PyExc_ValueError, "vec_step_many: k_steps must be positive"); return NULL; }
+    const size_t K = (size_t)k_steps;
+    const size_t need[5] = {K * h->n * DRONE_ACT_DIM * 4, K * h->n * h->obs_dim * 4, K * h->n * 4, K * h->n, K * h->n};
+    static const char* names[5] = {"actions", "observations", "rewards", "terminals", "truncations"};
+    void* ptr[5] = {0};
+    Py_buffer views[5];
+    int n_views = 0, ok = 1;
+    for (int i = 0; i < 5 && ok; i++) {
+        if (i == 0 && blk[0] == Py_None) continue; /* device policy */
+        void* d = NULL;
+        const int isdev = device_pointer(blk[i], &d);
+        if (isdev < 0) { ok = 0; break; }
+        if (isdev != h->device_kind) { PyErr_Format(PyExc_TypeError, "vec_step_many: %s must be of the env's buffer kind (host buffer / device tensor)", names[i]); ok = 0; break; }
+        if (isdev) {
+            if (check_device_tensor(blk[i], i < 3, need[i], names[i]) < 0) { ok = 0; break; }
+            ptr[i] = d;
+        } else {
+            if (PyObject_GetBuffer(blk[i], &views[n_views], (i == 0 ? 0 : PyBUF_WRITABLE) | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) { ok = 0; break; }
+            n_views++;
+            if ((size_t)views[n_views - 1].len < need[i]) { PyErr_Format(PyExc_ValueError, "vec_step_many: %s holds %zd bytes, %zu needed", names[i], views[n_views - 1].len, need[i]); ok = 0; break; }
+            if (check_host_format(&views[n_views - 1], i < 3, names[i]) < 0) { ok = 0; break; }
+            ptr[i] = views[n_views - 1].buf;
+        }
+    }
+    if (ok) {
+        Py_BEGIN_ALLOW_THREADS
+        drone_vec_step_many(h->v, k_steps, (const float*)ptr[0], (float*)ptr[1], (float*)ptr[2], (unsigned char*)ptr[3], (unsigned char*)ptr[4]);
+        Py_END_ALLOW_THREADS
+    }
+    for (int i = 0; i < n_views; i++) PyBuffer_Release(&views[i]);
+    if (!ok || raise_if_failed(h) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+/* vec_done_list_at(handle, k) -> bytes of uint32 ids (compact_done=1): envs that finished in step k of the last vec_step_many */
+static PyObject* vec_done_list_at(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    int k;
+    if (!PyArg_ParseTuple(args, "Oi", &cap, &k)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    uint32_t* ids = (uint32_t*)PyMem_Malloc(sizeof(uint32_t) * (h->n ? h->n : 1));
+    if (!ids) return PyErr_NoMemory();
+    const int cnt = drone_vec_done_list_at(h->v, k, ids, (int)h->n);
+    if (cnt < 0) { PyMem_Free(ids); PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
+    PyObject* out = PyBytes_FromStringAndSize((const char*)ids, (Py_ssize_t)sizeof(uint32_t) * cnt);
+    PyMem_Free(ids);
+    return out;
 }
 
 static PyObject* vec_log(PyObject* self, PyObject* args) {
@@ -300,9 +403,15 @@ static PyObject* vec_fill_random_actions(PyObject* self, PyObject* args) {
     } else {
         const int isdev = device_pointer(buf, &p);
         if (isdev < 0) return NULL;
-        if (!isdev) {
-            if (PyObject_GetBuffer(buf, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) return NULL;
+        if (isdev != h->device_kind) { PyErr_SetString(PyExc_TypeError, "vec_fill_random_actions: the buffer must be of the env's buffer kind (host buffer / device tensor)"); return NULL; }
+        const size_t need = h->n * DRONE_ACT_DIM * 4;  /* the library writes this many bytes through the pointer */
+        if (isdev) {
+            if (check_device_tensor(buf, 1, need, "actions") < 0) return NULL;
+        } else {
+            if (PyObject_GetBuffer(buf, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) return NULL;
             have_view = 1;
+            if ((size_t)view.len < need) { PyErr_Format(PyExc_ValueError, "vec_fill_random_actions: actions holds %zd bytes, %zu needed", view.len, need); PyBuffer_Release(&view); return NULL; }
+            if (check_host_format(&view, 1, "actions") < 0) { PyBuffer_Release(&view); return NULL; }
             p = view.buf;
         }
     }
@@ -334,6 +443,9 @@ static PyMethodDef methods[] = {
     {"vec_reset", vec_reset, METH_VARARGS, "vec_reset(handle, seed=0)"},
     {"vec_step", vec_step, METH_VARARGS, "vec_step(handle): read actions, advance every env, overwrite the output buffers"},
     {"vec_rollout", vec_rollout, METH_VARARGS, "vec_rollout(handle, horizon): fused rollout under the device-side random policy"},
+    {"vec_step_many", vec_step_many, METH_VARARGS,
+     "vec_step_many(handle, k_steps, actions | None, observations, rewards, terminals, truncations): K env steps in one launch, every step's outputs in K-major blocks"},
+    {"vec_done_list_at", vec_done_list_at, METH_VARARGS, "vec_done_list_at(handle, k) -> bytes (uint32 ids) of the envs that finished in step k of the last vec_step_many"},
     {"vec_log", vec_log, METH_VARARGS, "vec_log(handle) -> dict(perf, score, episode_return, episode_length, oob, n)"},
     {"vec_close", vec_close, METH_VARARGS, "vec_close(handle)"},
     {"vec_set_stream", vec_set_stream, METH_VARARGS, "vec_set_stream(handle, hip_stream_address)"},

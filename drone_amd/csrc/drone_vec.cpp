@@ -747,9 +747,12 @@ int drone_vec_sync(DroneVec* v) {
     return 0;
 }
 
+// Like every entry point that takes a handle, the two rebinds go through Entry: they may call hipHostUnregister (on the
+// handle's device, not whatever device the calling thread has current) and a failure sticks to the handle.
 int drone_vec_bind_actions(DroneVec* v, float* actions) {
-    g_err[0] = 0;
-    if (!v || !actions) { set_err("bind_actions: NULL argument"); return -1; }
+    Entry in(v);
+    if (!in) return -1;
+    if (!actions) { set_err("bind_actions: NULL argument"); return -1; }
     if (v->host_buffers) {
         if (v->zero_copy && actions != v->u_act) leave_zero_copy(v);  // an unregistered buffer: back to the mirror transport
         unpin_if_rebound(v, 1, actions);
@@ -763,8 +766,9 @@ int drone_vec_bind_actions(DroneVec* v, float* actions) {
 }
 
 int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, unsigned char* terminals, unsigned char* truncations) {
-    g_err[0] = 0;
-    if (!v || !observations || !rewards || !terminals || !truncations) { set_err("bind_outputs: NULL argument"); return -1; }
+    Entry in(v);
+    if (!in) return -1;
+    if (!observations || !rewards || !terminals || !truncations) { set_err("bind_outputs: NULL argument"); return -1; }
     if (!v->host_buffers) {
         if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
             set_err("device buffers must be 16-byte aligned (observations) and 4-byte aligned (rewards)");

@@ -121,3 +121,84 @@ def test_binding_device_tensors_and_rollout(ext, oracle):
     with pytest.raises(RuntimeError, match="horizon must be positive"):
         ext.vec_rollout(h, 0)
     del h  # capsule destructor closes the env
+
+
+def test_buffer_format_and_size_checks(ext):
+    """a buffer of sufficient byte length but the wrong item type (float64, int32) must be refused, not
+    written through a wrong layout; vec_fill_random_actions checks the size of what it is handed."""
+    b = host_buffers(16, 0)
+    with pytest.raises(TypeError, match="observations: expected float32"):
+        ext.vec_init(np.zeros((16, 20), np.float64), *b[1:], 16, 0)
+    with pytest.raises(TypeError, match="rewards: expected float32"):
+        ext.vec_init(b[0], b[1], np.zeros(16, np.int32), b[3], b[4], 16, 0)
+    with pytest.raises(TypeError, match="terminals: expected uint8"):
+        ext.vec_init(b[0], b[1], b[2], np.zeros(16, np.float32), b[4], 16, 0)
+    assert callable(ext.vec_step_many) and callable(ext.vec_done_list_at)
+
+
+@pytest.mark.gpu
+def test_fill_random_actions_refuses_an_undersized_buffer(ext):
+    n = 1024
+    h = ext.vec_init(*host_buffers(n, 0), n, 0)
+    ext.vec_reset(h, 0)
+    with pytest.raises(ValueError, match="actions holds"):
+        ext.vec_fill_random_actions(h, np.zeros((n // 2, 4), np.float32))  # the library would copy n*16 bytes into it
+    with pytest.raises(TypeError, match="expected float32"):
+        ext.vec_fill_random_actions(h, np.zeros((n, 4), np.float64))
+    ok = np.zeros((n, 4), np.float32)
+    ext.vec_fill_random_actions(h, ok, 5)
+    assert np.abs(ok).max() > 0
+    ext.vec_close(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,device", [(0, False), (1, True), (2, True), (3, False)])
+def test_binding_step_many_matches_oracle(ext, oracle, task, device):
+    """vec_step_many through the compiled binding: K in {1, 2, 7, 32} against K plain oracle steps, ragged env count."""
+    import torch
+
+    n, seed = 1000, 23
+    od = abi.obs_dim(task)
+    mk = (lambda *shape, dt=np.float32: np.zeros(shape, dt))
+    if device:
+        tmap = {np.float32: torch.float32, np.uint8: torch.uint8}
+        mk = (lambda *shape, dt=np.float32: torch.zeros(shape, dtype=tmap[dt], device="cuda:0"))
+    base = (mk(n, od), mk(n, 4), mk(n), mk(n, dt=np.uint8), mk(n, dt=np.uint8))
+    h = ext.vec_init(*base, n, seed, task=task, horizon=20, compact_done=1)
+    if device:
+        ext.vec_set_stream(h, torch.cuda.current_stream().cuda_stream)
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=8)
+    ext.vec_reset(h, seed)
+    o.reset(seed)
+    host = (lambda t: t.cpu().numpy() if device else t)
+    for K in (1, 2, 7, 32):
+        acts = np.stack([o.fill_random_actions(gstep=o.gstep + k).copy() for k in range(K)])
+        a_blk = mk(K, n, 4)
+        if device:
+            a_blk.copy_(torch.from_numpy(acts))
+        else:
+            a_blk[:] = acts
+        blocks = (mk(K, n, od), mk(K, n), mk(K, n, dt=np.uint8), mk(K, n, dt=np.uint8))
+        obs, rew, term, trunc, done = o.step_many(K, acts)
+        ext.vec_step_many(h, K, a_blk, *blocks)
+        if device:
+            torch.cuda.synchronize()
+        for k in range(K):
+            assert_bits_equal(obs[k], host(blocks[0])[k], f"K={K} obs {k}")
+            assert_bits_equal(rew[k], host(blocks[1])[k], f"K={K} rew {k}")
+            assert_bits_equal(term[k], host(blocks[2])[k], f"K={K} term {k}")
+            assert_bits_equal(trunc[k], host(blocks[3])[k], f"K={K} trunc {k}")
+            ids = np.sort(np.frombuffer(ext.vec_done_list_at(h, k), dtype=np.uint32))
+            assert_bits_equal(done[k], ids, f"K={K} done ids {k}")
+    assert ext.vec_gstep(h) == o.gstep == 42
+    # the random policy in the kernel (actions = None), and a short block refused
+    blocks = (mk(5, n, od), mk(5, n), mk(5, n, dt=np.uint8), mk(5, n, dt=np.uint8))
+    obs, rew, term, trunc, _ = o.step_many(5, None)
+    ext.vec_step_many(h, 5, None, *blocks)
+    if device:
+        torch.cuda.synchronize()
+    assert_bits_equal(obs, host(blocks[0]), "policy obs")
+    assert_bits_equal(rew, host(blocks[1]), "policy rew")
+    with pytest.raises(ValueError, match="observations holds"):
+        ext.vec_step_many(h, 6, None, *blocks)
+    ext.vec_close(h)

@@ -257,3 +257,65 @@ def test_state_rows_on_unaligned_subranges(hip, task):
         assert now.tobytes() == want.tobytes(), (first, count)
         full = want
     h.close()
+
+
+def test_rebinding_from_a_second_thread_while_another_handle_steps(oracle, hip):
+    """bind_actions / bind_outputs go through the entry guard (device switch + sticky status) like
+    every other call. Two host threads, one handle each (the library's threading contract): one steps its handle
+    back to back, the other rebinds action and output buffers on ITS handle before every step (host buffers, so each
+    rebind drops pins and leaves the zero-copy transport) — and a gather through the once-loaded RCCL table is opened
+    from both. Both trajectories must stay bit-exact against the oracle."""
+    import threading
+
+    n, steps = 3000, 120
+    errs = []
+
+    def stepper():
+        try:
+            o = oracle.OracleVec(n, seed=1, cfg=oracle.default_config(0, horizon=30), threads=2)
+            h = hip.DroneVec(n, seed=1, cfg=hip.default_config(0, horizon=30), device="cuda:0")
+            o.reset(1)
+            h.reset(1)
+            h.gather_init(hip.gather_unique_id(), 0, 1, *(t.clone() for t in (h.observations, h.rewards, h.terminals, h.truncations)))
+            for t in range(steps):
+                o.fill_random_actions()
+                h.fill_random_actions()
+                o.step()
+                h.step()
+            h.sync()
+            assert_outputs_equal(o, h, "stepping thread")
+            h.gather_close()
+            h.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(("stepper", repr(exc)))
+
+    def rebinder():
+        try:
+            o = oracle.OracleVec(n, seed=2, cfg=oracle.default_config(1, horizon=25), threads=2)
+            h = hip.DroneVec(n, seed=2, cfg=hip.default_config(1, horizon=25))  # host buffers
+            o.reset(2)
+            h.reset(2)
+            for t in range(steps):
+                o.fill_random_actions()
+                acts = o.actions.copy()  # a fresh, unpinned buffer every step: the pin on the previous one must go
+                outs = (np.zeros_like(h.observations), np.zeros_like(h.rewards), np.zeros_like(h.terminals), np.zeros_like(h.truncations))
+                h.bind_actions(acts)
+                h.bind_outputs(*outs)
+                o.step()
+                h.step()
+                assert_outputs_equal(o, h, f"rebinding thread, step {t}")
+            assert h.status() == (0, "")
+            with pytest.raises(RuntimeError, match="NULL"):
+                h._check(h._f["drone_vec_bind_actions"](h._h, None))
+            assert h.status()[0] != 0  # a failed rebind now sticks to the handle like any other failed call
+            h.clear_status()
+            h.close()
+        except Exception as exc:  # noqa: BLE001
+            errs.append(("rebinder", repr(exc)))
+
+    ts = [threading.Thread(target=stepper), threading.Thread(target=rebinder)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errs, errs

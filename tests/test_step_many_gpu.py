@@ -114,12 +114,15 @@ def test_step_many_done_lists(oracle, hip):
     check_call(o, h, small, 3, "lists K=3", lists=True)
     with pytest.raises(RuntimeError, match="outside the last step_many"):
         h.done_list_at(3)
+    assert h.status()[0] != 0  # like every failed call it sticks to the handle until cleared
+    h.clear_status()
     h.fill_random_actions()
     o.fill_random_actions()
     h.step()
     o.step()
     with pytest.raises(RuntimeError, match="not drone_vec_step_many"):
         h.done_list_at(0)
+    h.clear_status()
     assert_bits_equal(np.flatnonzero(o.terminals | o.truncations).astype(np.uint32), np.sort(h.done_list()), "plain done list after step_many")
 
 
