@@ -382,17 +382,18 @@ __device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L,
     __builtin_amdgcn_wave_barrier();
 }
 
-// steps 1-9 of one env step for any task (the swarm task looks at its neighbours in between)
-template <int TASK>
+// steps 1-9 of one env step for any task (the swarm task looks at its neighbours in between).
+// CARRY: the state stays in registers from step to step and carries the rotor inputs (Lane::u) with it.
+template <int TASK, bool CARRY = false>
 __device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     if (TASK == DRONE_TASK_SWARM) {
         StepCtx ctx;
-        lane_integrate<TASK>(P, L, act, env, gstep, ctx);
+        lane_integrate<TASK, CARRY>(P, L, act, env, gstep, ctx);
         float nn_d2, nn_e[3];
         swarm_neighbour(P, L, tile, nn_d2, nn_e);
-        lane_finish<TASK>(P, L, env, ctx, nn_d2, out);
+        lane_finish<TASK, CARRY>(P, L, env, ctx, nn_d2, out);
     } else {
-        lane_step<TASK>(P, L, act, env, gstep, out);
+        lane_step<TASK, CARRY>(P, L, act, env, gstep, out);
     }
 }
 
@@ -631,6 +632,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     const bool valid = i < n;
     Lane L;
     load_lane<TASK>(a.v.planes, a.v.n_pad, i, L);
+    L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
     float rsum = 0.0f;
@@ -639,7 +641,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, true>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -741,7 +743,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     if (POLICY) random_action(P.key_action, env, gstep, act);
     else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
     StepOut out;
-    step_any<TASK>(P, L, tile, act, env, gstep, out);
+    step_any<TASK, true>(P, L, tile, act, env, gstep, out);
     const bool ended = out.oob || out.trunc;
     any_target |= out.target_changed;
     any_end |= ended;
@@ -808,6 +810,7 @@ __global__ __launch_bounds__(kBlock) void drone_step_many_kernel(StepArgs a, Man
     const uint32_t i = block_base + threadIdx.x;
     Lane L;
     load_lane<TASK>(a.v.planes, a.v.n_pad, i, L);
+    L.u = rotor_inputs(P, L.s.r);  // carried through the K steps (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     bool any_target = false, any_end = false;
     if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform

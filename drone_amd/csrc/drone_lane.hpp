@@ -22,8 +22,18 @@ struct Dyn {
     float p[3], v[3], q[4], o[3], r[4];
 };
 
+// SPEC.md §4: what the rotors feed into the rigid body at one instant — twice the thrust acceleration and
+// the three body torques over the inertia.
+struct RotorIn {
+    float aT2, tx, ty, tz;
+};
+
 struct Lane {
     Dyn s;
+    RotorIn u;  // rotor inputs at the CURRENT rotor speeds s.r. Kernels that keep the state in registers from step to step
+                // (CARRY) maintain it: the inputs at the end of one substep are those at the start of the next — the same
+                // function of the same floats, so carrying them is bit-identical to recomputing them (18 operations saved
+                // per substep); kernels that load the state from HBM recompute it at the start of the step.
     float tgt[3];
     float wind[3];  // task 1: wind; task 3: unit normal of the current gate (the dynamics see no wind there)
     float ep_return;
@@ -57,11 +67,7 @@ DRONE_FN void unit3(const float (&e)[3], float (&out)[3]) {
     for (int i = 0; i < 3; i++) out[i] = e[i] * inv;
 }
 
-// SPEC.md §4: what the rotors feed into the rigid body at one instant — twice the thrust acceleration and
-// the three body torques over the inertia — from the rotor speeds at that instant. 18 operations.
-struct RotorIn {
-    float aT2, tx, ty, tz;
-};
+// SPEC.md §4: RotorIn from the rotor speeds at one instant. 18 operations.
 DRONE_FN RotorIn rotor_inputs(const KParams& P, const float (&r)[4]) {
     const float q0 = r[0] * r[0], q1 = r[1] * r[1], q2 = r[2] * r[2], q3 = r[3] * r[3];
     const float s01 = q0 + q1, s23 = q2 + q3;
@@ -110,8 +116,9 @@ DRONE_FN void deriv(const KParams& P, const Body& S, const RotorIn& u, const flo
 
 // SPEC.md §4: one substep of size h. Rotor speeds relax to cmd exactly (first-order lag, constant command), so the
 // rotor inputs are known functions of time: evaluated at t, t + h/2 (stages 2 and 3 share it) and t + h.
+// `u0`: rotor inputs at the substep's start (= at S.r) on entry, at its end on return.
 template <int TASK>
-DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3]) {
+DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u0) {
     float rh[4], rf[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -119,7 +126,7 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
         rh[i] = fma_(P.e_half, d, cmd[i]);
         rf[i] = fma_(P.e_full, d, cmd[i]);
     }
-    const RotorIn u0 = rotor_inputs(P, S.r), uh = rotor_inputs(P, rh), uf = rotor_inputs(P, rf);
+    const RotorIn uh = rotor_inputs(P, rh), uf = rotor_inputs(P, rf);
     Body B, k, A, acc;
 #pragma unroll
     for (int i = 0; i < 3; i++) { B.v[i] = S.v[i]; B.o[i] = S.o[i]; }
@@ -154,6 +161,7 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
 #undef STAGE4
 #pragma unroll
     for (int i = 0; i < 4; i++) S.r[i] = rf[i];
+    u0 = uf;
 }
 
 DRONE_FN float target_dist(const Lane& L) {
@@ -162,7 +170,7 @@ DRONE_FN float target_dist(const Lane& L) {
 }
 
 // SPEC.md §6. `env` is the global env id.
-template <int TASK = DRONE_TASK_HOVER>
+template <int TASK = DRONE_TASK_HOVER, bool CARRY = false>
 DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     const uint32_t b = rng_base(P.key_reset, env, L.episode);
     // nine values from five draws: 16-bit halves, low half first (SPEC.md §6)
@@ -197,6 +205,7 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
         const float e[3] = {L.tgt[0] - L.s.p[0], L.tgt[1] - L.s.p[1], L.tgt[2] - L.s.p[2]};
         unit3(e, L.wind);
     }
+    if (CARRY) L.u = rotor_inputs(P, L.s.r);  // the carried rotor inputs follow the fresh rotor speeds
 }
 
 // SPEC.md §2: the synthetic random policy.
@@ -217,7 +226,7 @@ struct StepCtx {
 };
 
 // SPEC.md §5 steps 1–4: actions, wind, RK4, renormalise, clamp, tick.
-template <int TASK>
+template <int TASK, bool CARRY = false>
 DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepCtx& ctx) {
     float a[4], cmd[4];
 #pragma unroll
@@ -244,7 +253,8 @@ DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], u
         ctx.prev_dist = target_dist(L);
     }
 
-    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind);
+    if (!CARRY) L.u = rotor_inputs(P, L.s.r);  // state fresh from HBM: nothing carried over from the previous step
+    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind, L.u);
 
     {
         float* q = L.s.q;
@@ -283,7 +293,7 @@ DRONE_FN void nearest_neighbour(const KParams& P, Other other, float& nn_d2, flo
 
 // SPEC.md §5 steps 5–9 (§10 steps 6–7 for the swarm task): distance, bounds,
 // reward, episode end and reset. `nn_d2` is read only by the swarm task.
-template <int TASK>
+template <int TASK, bool CARRY = false>
 DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx& ctx, float nn_d2, StepOut& out) {
     const float dist = target_dist(L);
     bool oob = !(fabsf(L.s.p[0]) <= P.bound) || !(fabsf(L.s.p[1]) <= P.bound) || !(fabsf(L.s.p[2]) <= P.bound);
@@ -356,18 +366,18 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
         out.ep_return = L.ep_return;
         out.ep_len = (float)L.tick;
         L.episode += 1u;
-        lane_reset<TASK>(P, L, env);
+        lane_reset<TASK, CARRY>(P, L, env);
         target_changed = true;
     }
     out.target_changed = target_changed;
 }
 
 // Single-agent tasks: the whole of SPEC.md §5 steps 1–9.
-template <int TASK>
+template <int TASK, bool CARRY = false>
 DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     StepCtx ctx;
-    lane_integrate<TASK>(P, L, act, env, gstep, ctx);
-    lane_finish<TASK>(P, L, env, ctx, 0.0f, out);
+    lane_integrate<TASK, CARRY>(P, L, act, env, gstep, ctx);
+    lane_finish<TASK, CARRY>(P, L, env, ctx, 0.0f, out);
 }
 
 // SPEC.md §7

@@ -101,8 +101,12 @@ DRONE_FN uint32_t rng_base(uint32_t key, uint32_t env, uint32_t ctr) {
     return hash32(hash32(key ^ env) + ctr * 0x9E3779B9u);
 }
 DRONE_FN uint32_t rng_draw(uint32_t base, uint32_t d) { return hash32(base + d * 0x85EBCA6Bu); }
-DRONE_FN float sym(uint32_t u) { return __builtin_fmaf(2.0f, (float)(u >> 8) * 5.9604645e-8f, -1.0f); }
-DRONE_FN float s16(uint32_t h) { return (float)((int)h - 32768) * 3.0517578125e-5f; }
+// SPEC.md §2 states sym(u) = 2 (u >> 8) 2^-24 - 1 and s16(h) = (h - 32768) 2^-15. Both are computed here as ONE fused
+// multiply-add on the converted integer: every intermediate of either form is exact (24- / 16-bit integers, powers of
+// two), so the two formulations round the same real number once and agree bit for bit (the oracle keeps the SPEC's
+// literal form: tests/test_lane_host.py compares them over all 2^16 halves); one operation fewer per value.
+DRONE_FN float sym(uint32_t u) { return __builtin_fmaf((float)(u >> 8), 1.1920928955078125e-7f, -1.0f); }
+DRONE_FN float s16(uint32_t h) { return __builtin_fmaf((float)h, 3.0517578125e-5f, -1.0f); }
 // j-th 16-bit half of a run of 32-bit draws, low half first
 DRONE_FN uint32_t half16(const uint32_t* u, uint32_t j) { return (j & 1u) ? (u[j >> 1] >> 16) : (u[j >> 1] & 0xFFFFu); }
 
