@@ -22,6 +22,12 @@ _SO = os.path.join(_DIR, "libdrone_oracle.so")
 _STAMP = os.path.join(_DIR, ".oracle_build_stamp")
 _lib = None
 _fns = None
+# C-ABI symbols the oracle library does not mirror (plumbing around the path, the exchange, the K-step form)
+_NOT_IN_ORACLE = (
+    "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_bind_outputs", "drone_vec_done_list",
+    "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error", "drone_device_count", "drone_vec_set_gstep", "drone_vec_enable_graph_capture", "drone_vec_status",
+    "drone_vec_status_message", "drone_vec_clear_status", "drone_gather_unique_id", "drone_vec_gather_init",
+    "drone_vec_gather", "drone_vec_gather_close", "drone_vec_step_many", "drone_vec_done_list_at", "drone_vec_gather_init_root")
 
 
 def _host_signature():
@@ -58,13 +64,7 @@ def lib():
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
-        names = [n for n in abi.SYMBOLS if n not in (
-            "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_bind_outputs", "drone_vec_done_list",
-            "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error", "drone_device_count", "drone_vec_set_gstep", "drone_vec_enable_graph_capture", "drone_vec_status",
-            "drone_vec_status_message", "drone_vec_clear_status", "drone_gather_unique_id", "drone_vec_gather_init",
-            "drone_vec_gather", "drone_vec_gather_close", "drone_vec_step_many", "drone_vec_done_list_at", "drone_vec_gather_init_root")]
-        _fns = abi.bind(_lib, prefix_to="oracle_", names=names)
-        _lib.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]
+        _fns = _bind(_lib)
         _lib.oracle_hash32.restype = C.c_uint32
         _lib.oracle_hash32.argtypes = [C.c_uint32]
         _lib.oracle_stream_key.restype = C.c_uint32
@@ -74,6 +74,23 @@ def lib():
         _lib.oracle_params_derive.argtypes = [C.POINTER(abi.DroneConfig), C.c_void_p]
         _lib.oracle_omp_max_threads.restype = C.c_int
     return _lib
+
+
+def _bind(cdll):
+    names = [n for n in abi.SYMBOLS if n not in _NOT_IN_ORACLE]
+    fns = abi.bind(cdll, prefix_to="oracle_", names=names)
+    cdll.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]
+    return fns
+
+
+def variant(cc, flags, out):
+    """Another build of the same oracle sources (tests: the golden vectors must come out bit for bit from every
+    compiler and optimisation level that honours the numerics contract, i.e. -ffp-contract=off and no fast-math).
+    Returns what ``OracleVec(..., fns=...)`` takes."""
+    src = os.path.join(_DIR, "drone_oracle_vec.c")
+    subprocess.run([cc, *flags, "-fPIC", "-shared", "-std=gnu11", "-o", out, src, "-lm"], check=True, capture_output=True)
+    cdll = C.CDLL(out)
+    return _bind(cdll), cdll
 
 
 def default_config(task=0, **overrides):
@@ -96,8 +113,9 @@ def params(cfg):
 class OracleVec:
     """Scalar C env looped over ``num_envs`` with numpy-owned buffers."""
 
-    def __init__(self, num_envs, seed=0, cfg=None, task=0, threads=1, **overrides):
+    def __init__(self, num_envs, seed=0, cfg=None, task=0, threads=1, fns=None, **overrides):
         lib()
+        self._f, self._l = (_fns, _lib) if fns is None else fns  # fns: another build of the oracle (`variant`)
         self.cfg = cfg if cfg is not None else default_config(task, **overrides)
         self.num_envs = int(num_envs)
         n = self.num_envs
@@ -106,21 +124,21 @@ class OracleVec:
         self.rewards = np.zeros(n, dtype=np.float32)
         self.terminals = np.zeros(n, dtype=np.uint8)
         self.truncations = np.zeros(n, dtype=np.uint8)
-        self._h = _fns["drone_vec_init"](
+        self._h = self._f["drone_vec_init"](
             self.observations.ctypes.data, self.actions.ctypes.data, self.rewards.ctypes.data,
             self.terminals.ctypes.data, self.truncations.ctypes.data, n, seed, C.byref(self.cfg))
         if not self._h:
             raise RuntimeError("oracle_vec_init failed")
-        _lib.oracle_set_threads(self._h, threads)
+        self._l.oracle_set_threads(self._h, threads)
 
     def reset(self, seed=0):
-        _fns["drone_vec_reset"](self._h, seed)
+        self._f["drone_vec_reset"](self._h, seed)
 
     def step(self):
-        _fns["drone_vec_step"](self._h)
+        self._f["drone_vec_step"](self._h)
 
     def rollout(self, horizon):
-        _fns["drone_vec_rollout"](self._h, horizon)
+        self._f["drone_vec_rollout"](self._h, horizon)
 
     def step_many(self, k_steps, actions=None):
         """What the product's drone_vec_step_many must reproduce: K plain c_step passes. ``actions`` [K][N][4], or None
@@ -144,35 +162,35 @@ class OracleVec:
     def fill_random_actions(self, gstep=None, out=None):
         out = self.actions if out is None else out
         g = self.gstep if gstep is None else gstep
-        _fns["drone_vec_fill_random_actions"](self._h, out.ctypes.data, g)
+        self._f["drone_vec_fill_random_actions"](self._h, out.ctypes.data, g)
         return out
 
     @property
     def gstep(self):
-        return _fns["drone_vec_gstep"](self._h)
+        return self._f["drone_vec_gstep"](self._h)
 
     def log(self):
         out = abi.DroneLog()
-        _fns["drone_vec_log"](self._h, C.byref(out))
+        self._f["drone_vec_log"](self._h, C.byref(out))
         return out.as_dict()
 
     def get_state(self, first=0, count=None):
         count = self.num_envs - first if count is None else count
         rows = np.zeros(count, dtype=abi.state_row_dtype())
-        rc = _fns["drone_vec_get_state"](self._h, rows.ctypes.data, first, count)
+        rc = self._f["drone_vec_get_state"](self._h, rows.ctypes.data, first, count)
         if rc != 0:
             raise RuntimeError("oracle get_state failed")
         return rows
 
     def set_state(self, rows, first=0):
         rows = np.ascontiguousarray(rows, dtype=abi.state_row_dtype())
-        rc = _fns["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows))
+        rc = self._f["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows))
         if rc != 0:
             raise RuntimeError("oracle set_state failed")
 
     def close(self):
         if self._h:
-            _fns["drone_vec_close"](self._h)
+            self._f["drone_vec_close"](self._h)
             self._h = None
 
     def __del__(self):

@@ -97,9 +97,36 @@ GOLDEN_CASES = [("hover", 0, 1024, 0, {}), ("waypoint", 1, 1024, 0, {}), ("hover
 
 @pytest.mark.parametrize("name,task,horizon,off,extra", GOLDEN_CASES)
 def test_oracle_reproduces_golden_vectors(oracle, name, task, horizon, off, extra):
+    check_golden(oracle, None, name, task, horizon, off, extra)
+
+
+# Every build that honours the numerics contract (-ffp-contract=off, no fast-math: only the fmaf() calls written in the
+# source fuse; / and sqrtf correctly rounded) must reproduce the committed vectors bit for bit — the vectors pin the
+# SOURCE's arithmetic, not one compiler's code generation. gcc and the image's clang (AMD clang 22, the same front end
+# hipcc uses for the kernels), each with and without optimisation, with and without hardware FMA / AVX code paths.
+COMPILERS = [("gcc", ["-O0"]), ("gcc", ["-O2", "-ffp-contract=off", "-fno-fast-math"]), ("gcc", ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fno-math-errno"]),
+             ("/opt/rocm/lib/llvm/bin/clang", ["-O0", "-ffp-contract=off"]), ("/opt/rocm/lib/llvm/bin/clang", ["-O3", "-ffp-contract=off", "-fno-fast-math"]),
+             ("/opt/rocm/lib/llvm/bin/clang", ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fno-math-errno"])]
+
+
+@pytest.fixture(scope="module", params=range(len(COMPILERS)), ids=[f"{os.path.basename(c)}{''.join(f)}" for c, f in COMPILERS])
+def other_build(request, oracle, tmp_path_factory):
+    cc, flags = COMPILERS[request.param]
+    if not (os.path.exists(cc) or cc == "gcc"):
+        pytest.skip(f"{cc} not in this image")
+    return oracle.variant(cc, flags, str(tmp_path_factory.mktemp("cc") / f"liboracle_{request.param}.so"))
+
+
+@pytest.mark.parametrize("name,task,horizon,off,extra", GOLDEN_CASES)
+def test_golden_vectors_from_every_compiler(oracle, other_build, name, task, horizon, off, extra):
+    """the oracle was only ever built with gcc -O3 -march=native."""
+    check_golden(oracle, other_build, name, task, horizon, off, extra)
+
+
+def check_golden(oracle, fns, name, task, horizon, off, extra):
     g = np.load(os.path.join(GOLD, f"golden_{name}.npz"))
     n, seed = 64, 20251017
-    v = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, horizon=horizon, env_offset=off, **extra), threads=2)
+    v = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(task, horizon=horizon, env_offset=off, **extra), threads=2, fns=fns)
     v.reset(seed)
     assert_state_equal(g["reset_state"], v.get_state(), "reset_state")
     assert_bits_equal(g["reset_obs"], v.observations, "reset_obs")
