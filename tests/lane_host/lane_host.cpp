@@ -118,6 +118,73 @@ void lane_host_step(const DroneConfig* cfg, uint64_t seed, uint32_t gstep, Drone
     write_obs(cfg, P, lanes, obs);
 }
 
+}  // extern "C"
+
+// T steps under the device policy with the lanes kept "in registers" from step to step, the way the fused rollout and
+// drone_vec_step_many run them: the rotor inputs are CARRIED across steps (Lane::u, CARRY = true) instead of being
+// recomputed from the rotor speeds at the start of every step. Returns the reward sums; rows are updated in place.
+template <int TASK>
+static void rollout_task(const KParams& P, std::vector<Lane>& lanes, DroneStateRow* rows, float* rsum, uint32_t gstep0, int T) {
+    const int n = (int)lanes.size();
+    std::vector<StepCtx> ctx(n);
+    std::vector<StepOut> outs(n);
+    std::vector<float> nn(n);
+    for (int i = 0; i < n; i++) lanes[i].u = rotor_inputs(P, lanes[i].s.r);
+    for (int t = 0; t < T; t++) {
+        for (int i = 0; i < n; i++) {
+            const uint32_t env = P.env_offset + (uint32_t)i;
+            float act[4];
+            random_action(P.key_action, env, gstep0 + (uint32_t)t, act);
+            if (TASK == DRONE_TASK_SWARM) lane_integrate<TASK, true>(P, lanes[i], act, env, gstep0 + (uint32_t)t, ctx[i]);
+            else lane_step<TASK, true>(P, lanes[i], act, env, gstep0 + (uint32_t)t, outs[i]);
+        }
+        if (TASK == DRONE_TASK_SWARM) {
+            for (int i = 0; i < n; i++) {
+                float e[3];
+                group_neighbour(P, lanes, i, nn[i], e);
+            }
+            for (int i = 0; i < n; i++) lane_finish<TASK, true>(P, lanes[i], P.env_offset + (uint32_t)i, ctx[i], nn[i], outs[i]);
+        }
+        for (int i = 0; i < n; i++) {
+            const StepOut& out = outs[i];
+            rsum[i] = rsum[i] + out.reward;
+            if (out.oob || out.trunc) {
+                rows[i].perf_sum += out.perf;
+                rows[i].score_sum += out.score;
+                rows[i].ret_sum += out.ep_return;
+                rows[i].len_sum += out.ep_len;
+                rows[i].n_sum += 1.0f;
+                rows[i].oob_sum += out.oob ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
+extern "C" {
+
+void lane_host_rollout(const DroneConfig* cfg, uint64_t seed, uint32_t gstep0, int T, DroneStateRow* rows, float* rsum, int n) {
+    KParams P;
+    derive_kparams(*cfg, seed, P);
+    std::vector<Lane> lanes(n);
+    for (int i = 0; i < n; i++) {
+        row_to_lane(rows[i], lanes[i]);
+        rsum[i] = 0.0f;
+    }
+    if (cfg->task == DRONE_TASK_HOVER) rollout_task<DRONE_TASK_HOVER>(P, lanes, rows, rsum, gstep0, T);
+    else if (cfg->task == DRONE_TASK_WAYPOINT) rollout_task<DRONE_TASK_WAYPOINT>(P, lanes, rows, rsum, gstep0, T);
+    else if (cfg->task == DRONE_TASK_RACE) rollout_task<DRONE_TASK_RACE>(P, lanes, rows, rsum, gstep0, T);
+    else rollout_task<DRONE_TASK_SWARM>(P, lanes, rows, rsum, gstep0, T);
+    for (int i = 0; i < n; i++) lane_to_row(lanes[i], rows[i]);
+}
+
+// s16 / sym as the product computes them (one fused multiply-add), for an exhaustive comparison with SPEC.md's literal forms
+void lane_host_s16_all(float* out65536) {
+    for (uint32_t h = 0; h < 65536u; h++) out65536[h] = s16(h);
+}
+void lane_host_sym(const uint32_t* u, float* out, int n) {
+    for (int i = 0; i < n; i++) out[i] = sym(u[i]);
+}
+
 void lane_host_kparams(const DroneConfig* cfg, uint64_t seed, uint32_t* out56) {
     KParams P;
     derive_kparams(*cfg, seed, P);

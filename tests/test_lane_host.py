@@ -59,6 +59,44 @@ def test_lane_math_bit_exact_vs_oracle(lane, oracle, task, horizon, substeps):
     assert rows["episode"].sum() > 0
 
 
+@pytest.mark.parametrize("task,horizon,substeps", [(0, 40, 1), (1, 33, 2), (2, 50, 1), (3, 45, 3)])
+def test_carried_rotor_inputs_equal_recomputed_ones(lane, oracle, task, horizon, substeps):
+    """The register-resident kernels (fused rollout, step_many) carry the rotor inputs from step to step and through
+    resets instead of recomputing them from the rotor speeds (round 3: 18 operations per substep). Same function of the
+    same floats: the carried form must give the oracle's rollout bit for bit, over hundreds of resets."""
+    n, seed = 768, 2718
+    extra = dict(collision_radius=0.6, agents_per_env=16, env_offset=784) if task == 2 else dict(env_offset=777)
+    cfg = oracle.default_config(task, horizon=horizon, substeps=substeps, **extra)
+    v = oracle.OracleVec(n, seed=seed, cfg=cfg, threads=4)
+    v.reset(seed)
+    rows = v.get_state()
+    rsum = np.zeros(n, np.float32)
+    for T in (1, 128, 37, 300):
+        g = v.gstep
+        v.rollout(T)
+        lane.lane_host_rollout(C.byref(cfg), C.c_uint64(seed), C.c_uint32(g), T, p(rows), p(rsum), n)
+        assert_state_equal(v.get_state(), rows, f"carried rollout T={T}")
+        assert_bits_equal(v.rewards, rsum, f"reward sums T={T}")
+    assert rows["episode"].sum() > 4 * n
+
+
+def test_fused_s16_and_sym_equal_the_specs_literal_forms(lane):
+    """SPEC.md §2: s16(h) = (h - 32768) 2^-15, sym(u) = 2 (u >> 8) 2^-24 - 1. The product computes each as one fused
+    multiply-add on the converted integer; all intermediates are exact either way, so they must agree on every input."""
+    got = np.zeros(65536, np.float32)
+    lane.lane_host_s16_all(p(got))
+    h = np.arange(65536, dtype=np.int64)
+    want = ((h - 32768).astype(np.float32) * np.float32(2.0 ** -15)).astype(np.float32)
+    assert_bits_equal(want, got, "s16 over all 2^16 halves")
+    rng = np.random.default_rng(1)
+    u = np.concatenate([rng.integers(0, 2**32, 1 << 20, dtype=np.uint64).astype(np.uint32), np.array([0, 255, 256, 0x7FFFFFFF, 0x80000000, 0x800000FF, 0xFFFFFFFF], np.uint32)])
+    out = np.zeros(len(u), np.float32)
+    lane.lane_host_sym(p(u), p(out), len(u))
+    m = (u >> 8).astype(np.float32)
+    want = (np.float32(2.0) * (m * np.float32(2.0 ** -24)) - np.float32(1.0)).astype(np.float32)  # 2 m 2^-24 and the subtraction are exact in float32
+    assert_bits_equal(want, out, "sym")
+
+
 def test_kparams_match_oracle_params(lane, oracle):
     cfg = oracle.default_config(1, substeps=3, dt=0.02)
     want = oracle.params(cfg)
