@@ -47,6 +47,7 @@ class DroneConfig(C.Structure):
         ("c_omega", _F), ("c_action", _F), ("crash_penalty", _F), ("progress_scale", _F), ("waypoint_bonus", _F),
         ("collision_radius", _F), ("proximity_radius", _F), ("c_proximity", _F),
         ("gate_radius", _F),
+        ("host_pages_exclusive", C.c_int32),
     ]
 
     def as_dict(self):
@@ -88,6 +89,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "drone_config_default": (None, [C.POINTER(DroneConfig), C.c_int]),
     "drone_obs_dim": (C.c_int, [C.c_int]),
+    "drone_vec_host_transport": (C.c_int, [_P]),
     "drone_device_count": (C.c_int, []),
     "drone_vec_init": (_P, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(DroneConfig)]),
     "drone_vec_reset": (None, [_P, C.c_uint64]),

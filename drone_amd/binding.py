@@ -66,6 +66,19 @@ def gather_unique_id():
     return bytes(buf)
 
 
+def page_buffer(shape, dtype):
+    """A zeroed numpy array that OWNS its pages: backed by an anonymous mapping of its own, so it starts on a page
+    boundary and nothing else lives in its pages (the mapping is padded to whole pages and stays alive as long as the
+    array does). Only such host buffers are pinned for the zero-copy transport — registering memory that shares a page
+    with other heap allocations trips a ROCm runtime fault (include/drone_vec.h: DroneConfig.host_pages_exclusive)."""
+    import mmap
+
+    count = int(np.prod(shape))
+    nbytes = max(1, count * np.dtype(dtype).itemsize)
+    m = mmap.mmap(-1, (nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE)
+    return np.frombuffer(m, dtype=dtype, count=count).reshape(shape)
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -124,11 +137,12 @@ class DroneVec:
         elif device is None:
             self.torch_device = None
             self.cfg.buffer_kind = abi.BUFFERS_HOST
-            self.observations = np.zeros((n, abi.obs_dim(self.cfg.task)), dtype=np.float32)
-            self.actions = np.zeros((n, abi.ACT_DIM), dtype=np.float32)
-            self.rewards = np.zeros(n, dtype=np.float32)
-            self.terminals = np.zeros(n, dtype=np.uint8)
-            self.truncations = np.zeros(n, dtype=np.uint8)
+            self.cfg.host_pages_exclusive = 1  # page_buffer: each array is a mapping of its own
+            self.observations = page_buffer((n, abi.obs_dim(self.cfg.task)), np.float32)
+            self.actions = page_buffer((n, abi.ACT_DIM), np.float32)
+            self.rewards = page_buffer((n,), np.float32)
+            self.terminals = page_buffer((n,), np.uint8)
+            self.truncations = page_buffer((n,), np.uint8)
         else:
             import torch
 
@@ -261,6 +275,13 @@ class DroneVec:
     @property
     def gstep(self):
         return self._f["drone_vec_gstep"](self._h)
+
+    @property
+    def host_transport(self):
+        """'zero-copy' (the kernel reads / writes the pinned host buffers over PCIe), 'mirror' (device mirrors +
+        copies), or None for device buffers."""
+        t = self._f["drone_vec_host_transport"](self._h)
+        return {1: "zero-copy", 0: "mirror"}.get(t)
 
     def enable_graph_capture(self, on=True):
         """Counters in HBM, advanced by the kernels: a captured step / rollout (torch.cuda.graph) replays correctly."""

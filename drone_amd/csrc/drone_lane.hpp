@@ -13,6 +13,19 @@
 
 #include "drone_params.hpp"
 
+// 1: the RK4 substep in two-wide f32 instructions with hand-placed modifiers (drone_pk.hpp); 0: scalar. Same results
+// bit for bit (same expression trees). Needs the constants in SGPRs: not with the LDS-staged constants variant.
+#ifndef DRONE_PK_RK4
+#define DRONE_PK_RK4 0
+#endif
+#if defined(DRONE_PARAMS_IN_LDS) && DRONE_PARAMS_IN_LDS
+#undef DRONE_PK_RK4
+#define DRONE_PK_RK4 0
+#endif
+#if DRONE_PK_RK4
+#include "drone_pk.hpp"
+#endif
+
 namespace drone {
 
 #define fma_(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -108,6 +121,160 @@ DRONE_FN void deriv(const KParams& P, const Body& S, const RotorIn& u, const flo
     D.q[3] = fma_(w, oz, fma_(x, oy, -(y * ox)));
 }
 
+#if DRONE_PK_RK4
+// ---------------------------------------------------------------------------------------------------------------
+// The substep in pair layout. Pairs (low, high):  V = (v0, v1)   X = (v2, o0)   O = (o1, o2)   Q = (q1, q2) = (x, y)
+// W = (q0, q3) = (w, z)   R01, R23 rotor speeds   U0 = (aT2, tx)   Utz = (ty, tz).
+// Rows that integrate with h (V, X, O) and with hq (Q, W) never share a pair; the step sizes travel as SGPR pairs
+// (h*, hq*) and each instruction picks its half. The W pair carries MINUS the derivative of q0 in its low lane
+// (SPEC: dq0 = -fma(x, ox, fma(y, oy, z oz))): the sign is applied by a neg modifier wherever that lane is consumed
+// (-(a + b) = (-a) + (-b) and fma(c, -k, -a) = -fma(c, k, a) hold exactly in IEEE arithmetic), which saves the four
+// negations per substep. 181 instructions (85 of them packed) instead of 266.
+// ---------------------------------------------------------------------------------------------------------------
+struct BodyPk {
+    pk::f2 V, X, O, Q, W;
+};
+struct RotorPk {
+    pk::f2 U0, Utz;
+};
+struct PkConsts {
+    pk::f2 hH, hF, hS, two, eHF, KD, G, C, dr;
+};
+// A constant on its way into an SGPR pair. The empty asm makes the value opaque: without it the optimiser merges the
+// loads of neighbouring KParams fields (kdy kdz, gyi gzi, ...) into <2 x float> loads of the kernarg block, and the
+// mixed vector / scalar view of that block then keeps 100 bytes of it in scratch memory, re-read inside the substep loop.
+DRONE_FN float sgpr_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(x));
+#endif
+    return x;
+}
+DRONE_FN PkConsts pk_consts(const KParams& P) {
+    PkConsts c;
+    c.hH = pk::make(sgpr_(P.h_half), sgpr_(P.hq_half));
+    c.hF = pk::make(sgpr_(P.h), sgpr_(P.hq));
+    c.hS = pk::make(sgpr_(P.h_sixth), sgpr_(P.hq_sixth));
+    c.two = pk::make(2.0f, 2.0f);
+    c.eHF = pk::make(sgpr_(P.e_half), sgpr_(P.e_full));
+    c.KD = pk::make(sgpr_(P.kdy), sgpr_(P.kdz));
+    c.G = pk::make(sgpr_(P.gyi), sgpr_(P.gzi));
+    c.C = pk::make(sgpr_(P.cy), sgpr_(P.cz));
+    c.dr = pk::make(sgpr_(P.drag_m), 0.0f);
+    return c;
+}
+
+// SPEC.md section 4 rotor inputs from the rotor-speed pairs: 12 instructions (18 scalar)
+DRONE_FN RotorPk rotor_inputs_pk(const KParams& P, const PkConsts& c, pk::f2 R01, pk::f2 R23) {
+    const pk::f2 Q01 = pk::mul(R01, R01), Q23 = pk::mul(R23, R23);  // (q0, q1), (q2, q3)
+    const float s01 = Q01.x + Q01.y, s23 = Q23.x + Q23.y;
+    RotorPk u;
+    u.U0 = pk::make(P.kT2_m * (s01 + s23), P.cx * (s01 - s23));
+    const pk::f2 A = pk::add_swap_lo(Q01, Q23);  // (q1 + q2, q0 + q2)
+    const pk::f2 B = pk::add_same_hi(Q01, Q23);  // (q0 + q3, q1 + q3)
+    u.Utz = pk::mul_s(c.C, pk::sub(A, B));       // (cy ((q1+q2) - (q0+q3)), cz ((q0+q2) - (q1+q3)))
+    return u;
+}
+
+// derivative of the 10 feedback components at state B under rotor inputs u: 27 instructions (34 scalar)
+template <int TASK>
+DRONE_FN void deriv_pk(const KParams& P, const PkConsts& c, const BodyPk& B, const RotorPk& u, const float (&wind)[3], BodyPk& K) {
+    const float x = B.Q.x, y = B.Q.y, w = B.W.x, z = B.W.y;
+    const float v2 = B.X.x, ox = B.X.y, oy = B.O.x, oz = B.O.y;
+    const pk::f2 t = pk::mul_lo_swap_nhi(B.W, B.Q);  // (w y, -(w x))
+    const pk::f2 Z = pk::fma_b_hi(B.Q, B.W, t);      // zx = fma(x, z, w y), zy = fma(y, z, -(w x))
+    const float zzh = 0.5f - fma_(x, x, y * y);
+    float dv2;
+    if (TASK == DRONE_TASK_WAYPOINT) {
+        const pk::f2 rel = pk::sub(B.V, pk::make_v(wind[0], wind[1]));
+        K.V = pk::fma_vlo_nc(u.U0, Z, pk::mul_slo(c.dr, rel));  // fma(aT2, z*, -(drag (v - wind)))
+        dv2 = fma_(-P.drag_m, v2 - wind[2], fma_(u.U0.x, zzh, -P.gravity));
+    } else {
+        K.V = pk::fma_vlo_nc(u.U0, Z, pk::mul_slo(c.dr, B.V));
+        dv2 = fma_(-P.drag_m, v2, fma_(u.U0.x, zzh, -P.gravity));
+    }
+    const float do0 = fma_(-P.gxi, oy * oz, fma_(-P.kdx, ox, u.U0.y));
+    K.X = pk::make(dv2, do0);
+    const pk::f2 m = pk::mul_swap_hi(B.O, B.X);                // (oz ox, oy ox)
+    K.O = pk::fma_ns(c.G, m, pk::fma_ns(c.KD, B.O, u.Utz));    // fma(-g, m, fma(-kd, o, t)) for rows y, z
+    const float nq0 = fma_(x, ox, fma_(y, oy, z * oz));       // = -dq0: the sign rides on the consumers' neg modifier
+    const float dq1 = fma_(w, ox, fma_(y, oz, -(z * oy)));
+    const float dq2 = fma_(w, oy, fma_(z, ox, -(x * oz)));
+    const float dq3 = fma_(w, oz, fma_(x, oy, -(y * ox)));
+    K.Q = pk::make(dq1, dq2);
+    K.W = pk::make(nq0, dq3);
+}
+
+#define DRONE_RK4_CONSTS(P) const PkConsts pkc_ = pk_consts(P);  // once per env step, outside the substep loop
+#define DRONE_RK4_EXTRA , pkc_
+template <int TASK>
+DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u0, const PkConsts& c) {
+    const pk::f2 C01 = pk::make_v(cmd[0], cmd[1]), C23 = pk::make_v(cmd[2], cmd[3]);
+    const pk::f2 d01 = pk::sub(pk::make_v(S.r[0], S.r[1]), C01), d23 = pk::sub(pk::make_v(S.r[2], S.r[3]), C23);
+    const pk::f2 rh01 = pk::fma_slo(c.eHF, d01, C01), rh23 = pk::fma_slo(c.eHF, d23, C23);  // rotor speeds at t + h/2
+    const pk::f2 rf01 = pk::fma_shi(c.eHF, d01, C01), rf23 = pk::fma_shi(c.eHF, d23, C23);  // and at t + h
+    RotorPk U;
+    U.U0 = pk::make_v(u0.aT2, u0.tx);
+    U.Utz = pk::make_v(u0.ty, u0.tz);
+    const RotorPk uh = rotor_inputs_pk(P, c, rh01, rh23), uf = rotor_inputs_pk(P, c, rf01, rf23);
+    BodyPk B, k, A, acc;
+    B.V = pk::make_v(S.v[0], S.v[1]);
+    B.X = pk::make_v(S.v[2], S.o[0]);
+    B.O = pk::make_v(S.o[1], S.o[2]);
+    B.Q = pk::make_v(S.q[1], S.q[2]);
+    B.W = pk::make_v(S.q[0], S.q[3]);
+    pk::f2 P01 = pk::make_v(S.p[0], S.p[1]);
+    // stage 1
+    deriv_pk<TASK>(P, c, B, U, wind, k);
+    pk::f2 pacc01 = B.V;
+    float pacc2 = B.X.x;
+    acc = k;
+#define DRONE_PK_STAGE_A(HP)                    \
+    A.V = pk::fma_slo(HP, k.V, B.V);            \
+    A.X = pk::fma_slo(HP, k.X, B.X);            \
+    A.O = pk::fma_slo(HP, k.O, B.O);            \
+    A.Q = pk::fma_shi(HP, k.Q, B.Q);            \
+    A.W = pk::fma_shi_nblo(HP, k.W, B.W);
+#define DRONE_PK_ACC2()                         \
+    acc.V = pk::fma_slo(c.two, k.V, acc.V);     \
+    acc.X = pk::fma_slo(c.two, k.X, acc.X);     \
+    acc.O = pk::fma_slo(c.two, k.O, acc.O);     \
+    acc.Q = pk::fma_slo(c.two, k.Q, acc.Q);     \
+    acc.W = pk::fma_slo(c.two, k.W, acc.W);
+    DRONE_PK_STAGE_A(c.hH)
+    // stage 2
+    deriv_pk<TASK>(P, c, A, uh, wind, k);
+    pacc01 = pk::fma_slo(c.two, A.V, pacc01);
+    pacc2 = fma_(2.0f, A.X.x, pacc2);
+    DRONE_PK_ACC2()
+    DRONE_PK_STAGE_A(c.hH)
+    // stage 3
+    deriv_pk<TASK>(P, c, A, uh, wind, k);
+    pacc01 = pk::fma_slo(c.two, A.V, pacc01);
+    pacc2 = fma_(2.0f, A.X.x, pacc2);
+    DRONE_PK_ACC2()
+    DRONE_PK_STAGE_A(c.hF)
+    // stage 4
+    deriv_pk<TASK>(P, c, A, uf, wind, k);
+    P01 = pk::fma_slo(c.hS, pk::add(pacc01, A.V), P01);
+    S.p[0] = P01.x;
+    S.p[1] = P01.y;
+    S.p[2] = fma_(P.h_sixth, pacc2 + A.X.x, S.p[2]);
+    const pk::f2 nV = pk::fma_slo(c.hS, pk::add(acc.V, k.V), B.V);
+    const pk::f2 nX = pk::fma_slo(c.hS, pk::add(acc.X, k.X), B.X);
+    const pk::f2 nO = pk::fma_slo(c.hS, pk::add(acc.O, k.O), B.O);
+    const pk::f2 nQ = pk::fma_shi(c.hS, pk::add(acc.Q, k.Q), B.Q);
+    const pk::f2 nW = pk::fma_shi_nblo(c.hS, pk::add(acc.W, k.W), B.W);
+#undef DRONE_PK_STAGE_A
+#undef DRONE_PK_ACC2
+    S.v[0] = nV.x; S.v[1] = nV.y; S.v[2] = nX.x;
+    S.o[0] = nX.y; S.o[1] = nO.x; S.o[2] = nO.y;
+    S.q[1] = nQ.x; S.q[2] = nQ.y; S.q[0] = nW.x; S.q[3] = nW.y;
+    S.r[0] = rf01.x; S.r[1] = rf01.y; S.r[2] = rf23.x; S.r[3] = rf23.y;
+    u0.aT2 = uf.U0.x; u0.tx = uf.U0.y; u0.ty = uf.Utz.x; u0.tz = uf.Utz.y;
+}
+#else
+#define DRONE_RK4_CONSTS(P)
+#define DRONE_RK4_EXTRA
 // one RK4 stage update over the 10 feedback components; the quaternion rows use the hq* steps
 #define DRONE_FOR_COMPONENTS(BODY)                                      \
     _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(v, i, h_) }    \
@@ -163,6 +330,8 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
     for (int i = 0; i < 4; i++) S.r[i] = rf[i];
     u0 = uf;
 }
+
+#endif  // DRONE_PK_RK4
 
 DRONE_FN float target_dist(const Lane& L) {
     const float dx = L.tgt[0] - L.s.p[0], dy = L.tgt[1] - L.s.p[1], dz = L.tgt[2] - L.s.p[2];
@@ -254,7 +423,8 @@ DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], u
     }
 
     if (!CARRY) L.u = rotor_inputs(P, L.s.r);  // state fresh from HBM: nothing carried over from the previous step
-    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind, L.u);
+    DRONE_RK4_CONSTS(P)
+    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind, L.u DRONE_RK4_EXTRA);
 
     {
         float* q = L.s.q;

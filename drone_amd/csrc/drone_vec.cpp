@@ -49,6 +49,23 @@ void set_err(const char* fmt, ...) {
 
 constexpr int kLogMaxGrid = 1024;
 
+// DRONE_DEBUG_REG=1: trace every host-memory registration the library makes or drops (stderr), to match a GPU memory
+// fault's address against what was mapped when
+bool debug_reg() {
+    static const bool on = [] { const char* e = getenv("DRONE_DEBUG_REG"); return e && *e && *e != '0'; }();
+    return on;
+}
+hipError_t host_register(void* p, size_t bytes, const void* who, const char* what) {
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (debug_reg()) fprintf(stderr, "[drone reg] + %p..%p %s of %p -> %s\n", p, (char*)p + bytes, what, who, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    return e;
+}
+void host_unregister(void* p, const void* who, const char* what) {
+    const hipError_t e = hipHostUnregister(p);
+    if (debug_reg()) fprintf(stderr, "[drone reg] - %p %s of %p -> %s\n", p, what, who, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    if (e != hipSuccess) (void)hipGetLastError();
+}
+
 }  // namespace
 
 struct DroneVec {
@@ -263,7 +280,7 @@ void* mapped_ptr(void* host) {
 // any later copy that touches those addresses again fail ("invalid argument": a range that is only partly pinned).
 void unpin_if_rebound(DroneVec* v, int slot, const void* now) {
     if (v->registered[slot] && v->registered_ptr[slot] != now) {
-        (void)hipHostUnregister(v->registered_ptr[slot]);
+        host_unregister(v->registered_ptr[slot], v, "rebound buffer");
         v->registered[slot] = false;
     }
 }
@@ -273,14 +290,35 @@ void leave_zero_copy(DroneVec* v) {
     v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
 }
 
-void try_register(DroneVec* v, int slot, void* p, size_t bytes) {
-    // Pin the caller's pages so the per-step copies are true async DMA. Not
-    // fatal if it fails (already pinned, or not page-lockable): pageable copies still work.
-    v->registered[slot] = (hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess);
-    v->registered_ptr[slot] = p;
-    if (!v->registered[slot]) (void)hipGetLastError();
+// Which caller host buffers may be pinned. hipHostRegister works at page granularity, and on ROCm 7 registering (and
+// later unregistering) a range that shares a page with OTHER heap memory breaks the runtime's own on-the-fly pinning of
+// pageable copy destinations on that page: a later hipMemcpy / torch .cpu() into a neighbouring allocation dies with
+// "Memory access fault by GPU ... on address <heap address>" (tools/debug/pageable_copy_stress.py reproduces it with
+// plain HIP calls; ~1 in 12 runs of this repo's GPU test suite hit it before this rule). So a buffer is registered only
+// when its pages are provably its own: it starts on a page boundary and either spans whole pages or the caller vouches
+// for the tail of the last page (cfg.host_pages_exclusive). Memory the caller pinned itself (hipHostMalloc,
+// hipHostRegister) is used as it is. Everything else is left alone and goes through plain pageable copies.
+constexpr uintptr_t kPage = 4096;
+
+bool already_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
 }
 
+// returns true if the buffer ends up pinned (by us: v->registered[slot]; or by its owner)
+bool pin_caller_buffer(DroneVec* v, int slot, void* p, size_t bytes) {
+    v->registered[slot] = false;
+    v->registered_ptr[slot] = p;
+    if (already_pinned(p)) return true;
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0;
+    const bool whole = (bytes % kPage) == 0;
+    if (!aligned || !(whole || v->cfg.host_pages_exclusive)) return false;
+    const size_t span = (bytes + kPage - 1) / kPage * kPage;
+    v->registered[slot] = (host_register(p, span, v, "caller buffer") == hipSuccess);
+    if (!v->registered[slot]) (void)hipGetLastError();
+    return v->registered[slot];
+}
 
 // ---------------------------------------------------------------------------
 // Host-boundary all-gather over RCCL (BASELINE.json north_star:
@@ -384,7 +422,7 @@ void gather_destroy(DroneVec* v) {
     }
     void* hosts[4] = {g->h_obs, g->h_rew, g->h_term, g->h_trunc};
     for (int k = 0; k < 4; k++)
-        if (g->h_registered[k]) (void)hipHostUnregister(hosts[k]);
+        if (g->h_registered[k]) host_unregister(hosts[k], v, "global gather buffer");
     if (g->own_staging) {
         (void)hipFree(g->g_obs);
         (void)hipFree(g->g_rew);
@@ -454,6 +492,8 @@ int drone_device_count(void) {
     return n;
 }
 
+int drone_vec_host_transport(const DroneVec* v) { return !v ? -1 : !v->host_buffers ? -1 : v->zero_copy ? 1 : 0; }
+
 int drone_obs_dim(int task) { return (task == DRONE_TASK_SWARM || task == DRONE_TASK_RACE) ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
 
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, unsigned char* terminals,
@@ -511,14 +551,13 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         INIT_TRY(hipMalloc((void**)&v->d_rew, n * sizeof(float)));
         INIT_TRY(hipMalloc((void**)&v->d_term, n));
         INIT_TRY(hipMalloc((void**)&v->d_trunc, n));
-        try_register(v, 0, observations, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float));
-        try_register(v, 1, actions, n * DRONE_ACT_DIM * sizeof(float));
-        try_register(v, 2, rewards, n * sizeof(float));
-        try_register(v, 3, terminals, n);
-        try_register(v, 4, truncations, n);
-        v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
         bool all_reg = true;
-        for (int i = 0; i < 5; i++) all_reg = all_reg && v->registered[i];
+        all_reg = pin_caller_buffer(v, 0, observations, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float)) && all_reg;
+        all_reg = pin_caller_buffer(v, 1, actions, n * DRONE_ACT_DIM * sizeof(float)) && all_reg;
+        all_reg = pin_caller_buffer(v, 2, rewards, n * sizeof(float)) && all_reg;
+        all_reg = pin_caller_buffer(v, 3, terminals, n) && all_reg;
+        all_reg = pin_caller_buffer(v, 4, truncations, n) && all_reg;
+        v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
         if (all_reg && want_zero_copy(num_envs)) {
             v->m_obs = (float*)mapped_ptr(observations);
             v->m_act = (float*)mapped_ptr(actions);
@@ -561,6 +600,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
 #undef INIT_TRY
+    if (debug_reg()) fprintf(stderr, "[drone reg] init %p n=%d %s%s obs=%p act=%p planes=%p\n", (void*)v, v->n, v->host_buffers ? "host" : "device", v->zero_copy ? " zero-copy" : "", (void*)observations, (void*)actions, (void*)v->dv.planes);
     return v;
 }
 
@@ -692,13 +732,14 @@ void drone_vec_log(DroneVec* v, DroneLog* out) {
 
 void drone_vec_close(DroneVec* v) {
     if (!v) return;
+    if (debug_reg()) fprintf(stderr, "[drone reg] close %p\n", (void*)v);
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     gather_destroy(v);
     for (int i = 0; i < 5; i++)
-        if (v->registered[i]) (void)hipHostUnregister(v->registered_ptr[i]);
+        if (v->registered[i]) host_unregister(v->registered_ptr[i], v, "caller buffer at close");
     (void)hipFree(v->dv.planes);
     (void)hipFree(v->dv.cold);
     (void)hipFree(v->d_kp);
@@ -1069,12 +1110,14 @@ int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, i
             // copy into the whole global buffer would then span pinned and pageable pages, which HIP rejects: drop the
             // local pins (the mirror transport does not need them) and pin the global buffers whole instead, best effort.
             for (int slot : {0, 2, 3, 4})
-                if (v->registered[slot]) { (void)hipHostUnregister(v->registered_ptr[slot]); v->registered[slot] = false; }
+                if (v->registered[slot]) { host_unregister(v->registered_ptr[slot], v, "local output (gather takes over)"); v->registered[slot] = false; }
             void* hosts[4] = {all_observations, all_rewards, all_terminals, all_truncations};
             const size_t bytes[4] = {g->total * od * sizeof(float), g->total * sizeof(float), g->total, g->total};
-            for (int k = 0; k < 4; k++) {
-                g->h_registered[k] = hipHostRegister(hosts[k], bytes[k], hipHostRegisterDefault) == hipSuccess;
-                if (!g->h_registered[k]) (void)hipGetLastError();
+            for (int k = 0; k < 4; k++) {  // pinned only when the pages are the buffer's own (pin_caller_buffer's rule)
+                const bool own_pages = (reinterpret_cast<uintptr_t>(hosts[k]) % kPage) == 0 && ((bytes[k] % kPage) == 0 || v->cfg.host_pages_exclusive);
+                g->h_registered[k] = own_pages && !already_pinned(hosts[k]) &&
+                                     host_register(hosts[k], (bytes[k] + kPage - 1) / kPage * kPage, v, "global gather buffer") == hipSuccess;
+                if (own_pages && !g->h_registered[k]) (void)hipGetLastError();
             }
 #define G_TRY(expr) HIP_TRY(expr, { gather_destroy(v); return -1; })
             G_TRY(hipMalloc((void**)&g->g_obs, g->total * od * sizeof(float)));

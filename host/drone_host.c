@@ -23,6 +23,16 @@
 
 #include "drone_vec.h"
 
+/* A zeroed buffer that owns its pages (page-aligned, padded to whole pages): what DroneConfig.host_pages_exclusive
+ * vouches for, so that the library may pin it for the zero-copy transport. */
+static void* page_alloc(size_t bytes) {
+    void* p = NULL;
+    const size_t span = (bytes + 4095) / 4096 * 4096;
+    if (posix_memalign(&p, 4096, span ? span : 4096) != 0) return NULL;
+    memset(p, 0, span ? span : 4096);
+    return p;
+}
+
 /* CRC-32 (IEEE 802.3, reflected, as zlib.crc32): crc of `buf` continuing from `crc` */
 static uint32_t crc32_update(uint32_t crc, const void* buf, size_t len) {
     static uint32_t table[256];
@@ -65,16 +75,17 @@ int main(int argc, char** argv) {
     }
     if (envs <= 0 || steps <= 0 || rollout <= 0) { fprintf(stderr, "--envs, --steps and --rollout must be positive\n"); return 2; }
     const size_t obs_dim = (size_t)drone_obs_dim(task); /* 20, or 24 for the swarm and race tasks */
-    float* obs = (float*)malloc(sizeof(float) * (size_t)envs * obs_dim);
-    float* act = (float*)malloc(sizeof(float) * (size_t)envs * DRONE_ACT_DIM);
-    float* rew = (float*)malloc(sizeof(float) * (size_t)envs);
-    unsigned char* term = (unsigned char*)malloc((size_t)envs);
-    unsigned char* trunc = (unsigned char*)malloc((size_t)envs);
+    float* obs = (float*)page_alloc(sizeof(float) * (size_t)envs * obs_dim);
+    float* act = (float*)page_alloc(sizeof(float) * (size_t)envs * DRONE_ACT_DIM);
+    float* rew = (float*)page_alloc(sizeof(float) * (size_t)envs);
+    unsigned char* term = (unsigned char*)page_alloc((size_t)envs);
+    unsigned char* trunc = (unsigned char*)page_alloc((size_t)envs);
     if (!obs || !act || !rew || !term || !trunc) { fprintf(stderr, "out of memory\n"); return 1; }
 
     DroneConfig cfg;
     drone_config_default(&cfg, task);
     cfg.buffer_kind = DRONE_BUFFERS_HOST;
+    cfg.host_pages_exclusive = 1; /* page_alloc: every buffer owns its pages */
     DroneVec* v = drone_vec_init(obs, act, rew, term, trunc, envs, seed, &cfg);
     if (!v) { fprintf(stderr, "drone_vec_init failed: %s\n", drone_last_error()); return 1; }
     drone_vec_reset(v, seed);

@@ -40,6 +40,16 @@
 
 #include "drone_vec.h"
 
+/* A zeroed buffer that owns its pages (page-aligned, padded to whole pages): what DroneConfig.host_pages_exclusive
+ * vouches for, so that the library may pin it for the zero-copy transport. */
+static void* page_alloc(size_t bytes) {
+    void* p = NULL;
+    const size_t span = (bytes + 4095) / 4096 * 4096;
+    if (posix_memalign(&p, 4096, span ? span : 4096) != 0) return NULL;
+    memset(p, 0, span ? span : 4096);
+    return p;
+}
+
 typedef struct Shared {
     volatile int id_ready;
     volatile int failed;
@@ -108,17 +118,21 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     const int n = counts[rank];
     const size_t od = (size_t)drone_obs_dim(o->task), total = (size_t)o->total;
     /* the whole batch in host memory on every rank; the local buffers are this rank's slice of it */
-    float* all_obs = (float*)malloc(sizeof(float) * total * od);
-    float* all_rew = (float*)malloc(sizeof(float) * total);
-    unsigned char* all_term = (unsigned char*)malloc(total);
-    unsigned char* all_trunc = (unsigned char*)malloc(total);
-    float* act = (float*)malloc(sizeof(float) * (size_t)n * DRONE_ACT_DIM);
+    float* all_obs = (float*)page_alloc(sizeof(float) * total * od);
+    float* all_rew = (float*)page_alloc(sizeof(float) * total);
+    unsigned char* all_term = (unsigned char*)page_alloc(total);
+    unsigned char* all_trunc = (unsigned char*)page_alloc(total);
+    float* act = (float*)page_alloc(sizeof(float) * (size_t)n * DRONE_ACT_DIM);
     if (!all_obs || !all_rew || !all_term || !all_trunc || !act) { fprintf(stderr, "rank %d: out of memory\n", rank); return 1; }
     memset(all_obs, 0, sizeof(float) * total * od);
 
     DroneConfig cfg;
     drone_config_default(&cfg, o->task);
     cfg.buffer_kind = DRONE_BUFFERS_HOST;
+    /* The four global buffers come from page_alloc (each owns its pages), so the gather may pin them whole; this rank's
+     * local output buffers are SLICES of them at arbitrary offsets and share pages with the neighbours' rows — with one
+     * rank the slice is the whole buffer, with several it is not, and the library then simply copies (mirror transport). */
+    cfg.host_pages_exclusive = world == 1 ? 1 : 0;
     cfg.device = rank; /* one process per GPU */
     if (o->share) {
         const int ndev = drone_device_count();

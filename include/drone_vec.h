@@ -38,7 +38,7 @@ extern "C" {
 #define DRONE_TASK_SWARM 2    /* agents_per_env drones per env, coupled by a nearest-neighbour term (SPEC.md §10) */
 #define DRONE_TASK_RACE 3     /* fly through a sequence of ring gates (SPEC.md §11) */
 
-#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory: registered + mapped, the kernel accesses them over PCIe (fallback: H2D, kernel, D2H); step ends with a sync */
+#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory. Buffers that own their pages (see host_pages_exclusive) are pinned + mapped and the kernel accesses them over PCIe; any others go through H2D, kernel, D2H copies; step ends with a sync */
 #define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
 
 /* Env kwargs. Fill with drone_config_default() first, then override. */
@@ -62,6 +62,15 @@ typedef struct DroneConfig {
     float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
     float collision_radius, proximity_radius, c_proximity; /* task 2 */
     float gate_radius;                                      /* task 3 */
+    /* Host buffers only. 1: the caller guarantees that each of the five buffers starts on a 4 KiB page boundary and
+     * that nothing else lives in its pages up to the end of its last page (its own mmap / posix_memalign block, padded
+     * to whole pages). Such buffers are pinned and mapped for the zero-copy transport. 0 (default): a buffer is pinned
+     * only if it is page-aligned AND a whole number of pages long, or already pinned by the caller (hipHostMalloc /
+     * hipHostRegister); everything else is copied through pageable transfers and never registered. Why: on ROCm 7,
+     * hipHostRegister / hipHostUnregister of a range that SHARES a page with other heap memory breaks the runtime's
+     * own on-the-fly pinning of pageable copy destinations on that page ("Memory access fault by GPU ... on address
+     * <heap address>", tools/debug/pageable_copy_stress.py reproduces it without this library). */
+    int32_t host_pages_exclusive;
 } DroneConfig;
 
 /* Aggregated episode statistics since the previous drone_vec_log (SPEC.md §8). */
@@ -90,6 +99,10 @@ void drone_config_default(DroneConfig* cfg, int task);
 
 /* HIP devices visible to this process (0 if none / HIP unusable); a multi-process host maps ranks onto them. */
 int drone_device_count(void);
+
+/* 1 if host-buffer steps of this handle run zero-copy (kernel reads / writes the caller's pinned buffers over PCIe),
+ * 0 if they go through device mirrors and copies; -1 for device-buffer handles. */
+int drone_vec_host_transport(const DroneVec* v);
 
 /* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM and DRONE_TASK_RACE. */
 int drone_obs_dim(int task);

@@ -18,11 +18,15 @@ SRC = os.path.join(HERE, "lane_host", "lane_host.cpp")
 SO = os.path.join(HERE, "lane_host", "liblane_host.so")
 
 
-@pytest.fixture(scope="module")
-def lane():
+# Both forms of the RK4 substep: scalar, and the two-wide one (drone_pk.hpp; on the host its packed operations are the
+# same expression trees as plain scalar code, so these tests pin the trees — pair layout, half selection, the carried
+# sign of dq0 — against the oracle before the gfx950 build is ever run).
+@pytest.fixture(scope="module", params=[0, 1], ids=["scalar_rk4", "packed_rk4"])
+def lane(request):
+    so = SO.replace(".so", f"_pk{request.param}.so")
     subprocess.run(["g++", "-O2", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-shared",
-                    "-o", SO, SRC], check=True)
-    return C.CDLL(SO)
+                    f"-DDRONE_PK_RK4={request.param}", "-o", so, SRC], check=True)
+    return C.CDLL(so)
 
 
 def p(a):

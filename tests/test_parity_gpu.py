@@ -344,6 +344,7 @@ def test_host_buffer_transports(oracle, hip, zero_copy, monkeypatch):
     the kernel accessing the caller's registered numpy buffers over PCIe (=1)."""
     monkeypatch.setenv("DRONE_HOST_ZEROCOPY", zero_copy)
     o, h = make_pair(oracle, hip, 5000, 41, 1, horizon=50)
+    assert h.host_transport == ("zero-copy" if zero_copy == "1" else "mirror")  # the binding's own buffers own their pages
     for t in range(150):
         o.fill_random_actions()
         h.actions[:] = o.actions
@@ -364,6 +365,7 @@ def test_host_buffer_transports(oracle, hip, zero_copy, monkeypatch):
         o.step()
         h.step()
     assert_outputs_equal(o, h, "after rebinding")
+    assert h.host_transport == "mirror"
     assert_state_equal(o.get_state(), h.get_state(), "host transport state")
 
 

@@ -319,3 +319,66 @@ def test_rebinding_from_a_second_thread_while_another_handle_steps(oracle, hip):
     for t in ts:
         t.join(300)
     assert not errs, errs
+
+
+def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip):
+    """Host buffers are registered (zero-copy transport) only when their pages are provably theirs; anything else is
+    copied and never registered. All three cases step bit-exactly."""
+    n, seed = 4096, 5  # 4096 envs: every buffer is a whole number of pages
+    mk = lambda alloc: (alloc((n, 20), np.float32), alloc((n, 4), np.float32), alloc((n,), np.float32), alloc((n,), np.uint8), alloc((n,), np.uint8))
+    cases = [("binding's own page buffers", None, "zero-copy"),
+             ("caller's heap arrays (np.zeros): share pages with other allocations", mk(lambda s, d: np.zeros(s, d)), "mirror"),
+             ("caller's page-aligned whole-page arrays, no flag", mk(hip.page_buffer), "zero-copy")]
+    for what, bufs, want in cases:
+        o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(1, horizon=25), threads=4)
+        h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25), buffers=bufs) if bufs is not None else hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25))
+        assert h.host_transport == want, what
+        o.reset(seed)
+        h.reset(seed)
+        for t in range(60):
+            o.fill_random_actions()
+            h.actions[:] = o.actions
+            o.step()
+            h.step()
+        assert_outputs_equal(o, h, what)
+        h.close()
+    # a ragged env count with caller heap arrays that happen to be page-aligned at the start only: not pinned without the flag
+    m = 1000
+    base = hip.page_buffer((m, 20), np.float32)
+    h = hip.DroneVec(m, seed=seed, cfg=hip.default_config(0), buffers=(base, np.zeros((m, 4), np.float32), np.zeros(m, np.float32), np.zeros(m, np.uint8), np.zeros(m, np.uint8)))
+    assert h.host_transport == "mirror"
+    h.close()
+
+
+def test_host_handles_beside_pageable_copies_do_not_fault(hip):
+    """Regression for the ROCm interaction that killed ~1 in 12 runs of this suite ("Memory access fault by GPU ... on
+    address <heap address>"): hipHostRegister / hipHostUnregister of heap buffers that share pages with other
+    allocations, beside the runtime's own on-the-fly pinning of pageable copy destinations (torch .cpu()). Host handles
+    over plain heap arrays are created, stepped and closed in a loop with pageable copies in between; since such
+    buffers are no longer registered the loop must survive (tools/debug/pageable_copy_stress.py is the library-free
+    reproducer: it faults within seconds in 'reg' mode and never in 'reg_aligned' mode)."""
+    import time
+
+    import torch
+
+    rng = np.random.default_rng(0)
+    dev = [torch.randn(k, device="cuda") for k in (5000, 60000, 400000, 1 << 20)]
+    keep = []
+    t0 = time.time()
+    it = 0
+    while time.time() - t0 < 12.0:
+        it += 1
+        n = int(rng.integers(64, 3000))
+        bufs = (np.zeros((n, 20), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+        h = hip.DroneVec(n, seed=it, cfg=hip.default_config(0), buffers=bufs)
+        h.reset(it)
+        h.step()
+        x = dev[it % 4].cpu()
+        y = np.empty(int(rng.integers(1000, 2_000_000)), np.float32)
+        y[: min(len(y), x.numel())] = x.numpy()[: min(len(y), x.numel())]
+        h.close()
+        keep.append(y)
+        if len(keep) > int(rng.integers(1, 40)):
+            keep.clear()
+    torch.cuda.synchronize()
+    assert it > 100

@@ -28,7 +28,8 @@ def main():
     ap.add_argument("--task", default="hover")
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--mode", default="step", choices=["step", "rollout"])
+    ap.add_argument("--mode", default="step", choices=["step", "rollout", "many"])
+    ap.add_argument("--k", type=int, default=32, help="--mode many: env steps per launch (reported per env step)")
     ap.add_argument("--horizon", type=int, default=128)
     ap.add_argument("--fresh", action="store_true")
     ap.add_argument("--ring", type=int, default=4)
@@ -109,11 +110,25 @@ def main():
                 v.bind_actions(ring[k % len(ring)])
                 v.step()
             return v.timer_stop() * 1e3 / a.steps
-        v.rollout(a.horizon)
+        if a.mode == "many":
+            bufs = v.alloc_step_many(a.k)
+            for k in range(a.k):
+                bufs.actions[k].copy_(ring[k % len(ring)])
+            reps = max(4, a.steps // a.k)
+            for _ in range(3):
+                v.step_many(bufs)
+            torch.cuda.synchronize()
+            v.timer_start()
+            for _ in range(reps):
+                v.step_many(bufs)
+            return v.timer_stop() * 1e3 / (reps * a.k)
+        for _ in range(30):  # a pure-VALU kernel follows the clock transient of a GPU leaving idle
+            v.rollout(a.horizon)
         torch.cuda.synchronize()
         v.timer_start()
-        v.rollout(a.horizon)
-        return v.timer_stop() * 1e3
+        for _ in range(10):
+            v.rollout(a.horizon)
+        return v.timer_stop() * 1e3 / 10
 
     times = {k: [] for k in specs}
     live = {k: make(k) for k in specs} if a.fresh else None
