@@ -31,6 +31,8 @@
 // /root/reference — .gitmodules:1-3).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "drone_kernels.h"
 #include "drone_lane.hpp"
 
@@ -384,16 +386,17 @@ __device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L,
 
 // steps 1-9 of one env step for any task (the swarm task looks at its neighbours in between).
 // CARRY: the state stays in registers from step to step and carries the rotor inputs (Lane::u) with it.
-template <int TASK, bool CARRY = false>
+// PK: the RK4 substep in packed f32 instructions (small shards; drone_pk.hpp).
+template <int TASK, bool CARRY = false, bool PK = false>
 __device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     if (TASK == DRONE_TASK_SWARM) {
         StepCtx ctx;
-        lane_integrate<TASK, CARRY>(P, L, act, env, gstep, ctx);
+        lane_integrate<TASK, CARRY, PK>(P, L, act, env, gstep, ctx);
         float nn_d2, nn_e[3];
         swarm_neighbour(P, L, tile, nn_d2, nn_e);
         lane_finish<TASK, CARRY>(P, L, env, ctx, nn_d2, out);
     } else {
-        lane_step<TASK, CARRY>(P, L, act, env, gstep, out);
+        lane_step<TASK, CARRY, PK>(P, L, act, env, gstep, out);
     }
 }
 
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
 #define DRONE_ROLLOUT_WAVES
 #endif
 
-template <int TASK>
+template <int TASK, bool PK>
 __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -641,7 +644,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK, true>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, true, PK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -731,7 +734,7 @@ __device__ __forceinline__ void write_outputs_wave(float4* tile, float* obs_wave
 
 // one env step of the K: everything between "action row in registers" and "outputs of step k issued".
 // FULL: every lane of this workgroup is a real env (all but the last workgroup of a ragged shard).
-template <int TASK, bool COMPACT, bool POLICY, bool FULL>
+template <int TASK, bool COMPACT, bool POLICY, bool FULL, bool PK>
 __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const StepArgs& a, const ManyArgs& m, Lane& L, float4& l0, float4& l1,
                                           const float4& arow, uint32_t k, uint32_t gstep, uint32_t i, uint32_t block_base, bool& any_target, bool& any_end) {
     const uint32_t n = a.v.n;
@@ -743,7 +746,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     if (POLICY) random_action(P.key_action, env, gstep, act);
     else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
     StepOut out;
-    step_any<TASK, true>(P, L, tile, act, env, gstep, out);
+    step_any<TASK, true, PK>(P, L, tile, act, env, gstep, out);
     const bool ended = out.oob || out.trunc;
     any_target |= out.target_changed;
     any_end |= ended;
@@ -780,7 +783,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     }
 }
 
-template <int TASK, bool COMPACT, bool POLICY, bool FULL>
+template <int TASK, bool COMPACT, bool POLICY, bool FULL, bool PK>
 __device__ __forceinline__ void many_loop(const KParams& P, Shared& sh, const StepArgs& a, const ManyArgs& m, Lane& L, float4& l0, float4& l1,
                                           uint32_t gstep0, uint32_t i, uint32_t block_base, bool& any_target, bool& any_end) {
     const uint32_t n = a.v.n, K = m.k_steps;
@@ -792,16 +795,24 @@ __device__ __forceinline__ void many_loop(const KParams& P, Shared& sh, const St
         a_nxt = actp[(size_t)min(1u, K - 1u) * n];
     }
     // step 0, peeled: the loop below is entered with step 0's stores behind the load of a_nxt, like every later entry
-    many_step<TASK, COMPACT, POLICY, FULL>(P, sh, a, m, L, l0, l1, a_cur, 0u, gstep0, i, block_base, any_target, any_end);
+    many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, 0u, gstep0, i, block_base, any_target, any_end);
     for (uint32_t k = 1; k < K; k++) {
         a_cur = a_nxt;
         if (!POLICY) a_nxt = actp[(size_t)min(k + 1u, K - 1u) * n];  // the NEXT step's row: in flight during this step's arithmetic
-        many_step<TASK, COMPACT, POLICY, FULL>(P, sh, a, m, L, l0, l1, a_cur, k, gstep0 + k, i, block_base, any_target, any_end);
+        many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, k, gstep0 + k, i, block_base, any_target, any_end);
     }
 }
 
-template <int TASK, bool COMPACT, bool POLICY>
-__global__ __launch_bounds__(kBlock) void drone_step_many_kernel(StepArgs a, ManyArgs m) {
+#ifndef DRONE_MANY_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the K-steps-per-launch kernel; 0 = unset
+#define DRONE_MANY_MIN_WAVES 0
+#endif
+#if DRONE_MANY_MIN_WAVES > 0
+#define DRONE_MANY_BOUNDS __launch_bounds__(kBlock, DRONE_MANY_MIN_WAVES)
+#else
+#define DRONE_MANY_BOUNDS __launch_bounds__(kBlock)
+#endif
+template <int TASK, bool COMPACT, bool POLICY, bool PK>
+__global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
@@ -813,8 +824,8 @@ __global__ __launch_bounds__(kBlock) void drone_step_many_kernel(StepArgs a, Man
     L.u = rotor_inputs(P, L.s.r);  // carried through the K steps (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     bool any_target = false, any_end = false;
-    if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
-    else many_loop<TASK, COMPACT, POLICY, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard
+    if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true, PK>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
+    else many_loop<TASK, COMPACT, POLICY, false, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard (one workgroup: scalar form, less code)
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
     store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)));
     if (lane_bit(whole_lines(__ballot(any_end), a.v.line_complete))) {
@@ -887,10 +898,8 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
 
 inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
-// hipGetLastError() reports the calling thread's last runtime error, whoever caused it (another library's call that
-// failed benignly, a query that returned not-ready). Drop anything stale first so that what a launch_* returns is
-// the launch's own status.
-inline void drop_stale_error() { (void)hipGetLastError(); }
+// The packed-f32 RK4 form for the register-resident kernels: chosen per handle by the host (DeviceView::packed_rk4)
+inline bool use_packed(const DeviceView& v) { return DRONE_PK_RK4 && v.packed_rk4 != 0; }
 
 }  // namespace
 
@@ -928,10 +937,13 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     drop_stale_error();
     const StepArgs a = make_args(v, gstep0);
     const dim3 g(grid_for(v.n)), b(kBlock);
-    if (task == DRONE_TASK_HOVER) drone_rollout_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(a, horizon);
-    else if (task == DRONE_TASK_SWARM) drone_rollout_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(a, horizon);
-    else if (task == DRONE_TASK_RACE) drone_rollout_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(a, horizon);
-    else drone_rollout_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(a, horizon);
+    const bool pk = use_packed(v);
+#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon); } while (0)
+    if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_HOVER);
+    else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_SWARM);
+    else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_RACE);
+    else DRONE_LAUNCH_ROLLOUT(DRONE_TASK_WAYPOINT);
+#undef DRONE_LAUNCH_ROLLOUT
     return hipGetLastError();
 }
 
@@ -943,17 +955,19 @@ hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint
     m.act = act; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
     m.done_ids = done_ids; m.done_count = done_count; m.k_steps = k_steps;
     const dim3 g(grid_for(v.n)), b(kBlock);
-    const bool compact = done_ids != nullptr, policy = act == nullptr;
+    const bool compact = done_ids != nullptr, policy = act == nullptr, pk = use_packed(v);
+#define DRONE_LAUNCH_MANY2(T, C, PO) do { if (pk) drone_step_many_kernel<T, C, PO, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, C, PO, false><<<g, b, 0, s>>>(a, m); } while (0)
 #define DRONE_LAUNCH_MANY(T)                                                                 \
     do {                                                                                     \
-        if (compact) { if (policy) drone_step_many_kernel<T, true, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, true, false><<<g, b, 0, s>>>(a, m); } \
-        else { if (policy) drone_step_many_kernel<T, false, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, false, false><<<g, b, 0, s>>>(a, m); }    \
+        if (compact) { if (policy) DRONE_LAUNCH_MANY2(T, true, true); else DRONE_LAUNCH_MANY2(T, true, false); } \
+        else { if (policy) DRONE_LAUNCH_MANY2(T, false, true); else DRONE_LAUNCH_MANY2(T, false, false); }    \
     } while (0)
     if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_MANY(DRONE_TASK_HOVER);
     else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_MANY(DRONE_TASK_SWARM);
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_MANY(DRONE_TASK_RACE);
     else DRONE_LAUNCH_MANY(DRONE_TASK_WAYPOINT);
 #undef DRONE_LAUNCH_MANY
+#undef DRONE_LAUNCH_MANY2
     return hipGetLastError();
 }
 

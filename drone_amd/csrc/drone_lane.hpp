@@ -13,10 +13,17 @@
 
 #include "drone_params.hpp"
 
-// 1: the RK4 substep in two-wide f32 instructions with hand-placed modifiers (drone_pk.hpp); 0: scalar. Same results
-// bit for bit (same expression trees). Needs the constants in SGPRs: not with the LDS-staged constants variant.
+// The RK4 substep exists twice: scalar, and in two-wide f32 instructions with hand-placed modifiers (drone_pk.hpp).
+// Same results bit for bit (same expression trees). Which one runs is a template argument (PK) that the kernels choose
+// at launch: packed wins where a SIMD holds one or two waves (65 536 envs: fused rollout -8.6 %, step_many -5.8 %) and
+// loses once the chip is full (2^20 envs: rollout +8.9 %) — profiles/r03_ab/ab_pk_*.txt.
+// DRONE_PK_RK4=0 compiles the packed form out (it needs the constants in SGPRs: not with the LDS-staged constants variant).
+// DRONE_PK_DEFAULT: what PK defaults to where the caller does not say (the host test harness builds once with each).
 #ifndef DRONE_PK_RK4
-#define DRONE_PK_RK4 0
+#define DRONE_PK_RK4 1
+#endif
+#ifndef DRONE_PK_DEFAULT
+#define DRONE_PK_DEFAULT 0
 #endif
 #if defined(DRONE_PARAMS_IN_LDS) && DRONE_PARAMS_IN_LDS
 #undef DRONE_PK_RK4
@@ -204,10 +211,8 @@ DRONE_FN void deriv_pk(const KParams& P, const PkConsts& c, const BodyPk& B, con
     K.W = pk::make(nq0, dq3);
 }
 
-#define DRONE_RK4_CONSTS(P) const PkConsts pkc_ = pk_consts(P);  // once per env step, outside the substep loop
-#define DRONE_RK4_EXTRA , pkc_
 template <int TASK>
-DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u0, const PkConsts& c) {
+DRONE_FN void rk4_substep_pk(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u0, const PkConsts& c) {
     const pk::f2 C01 = pk::make_v(cmd[0], cmd[1]), C23 = pk::make_v(cmd[2], cmd[3]);
     const pk::f2 d01 = pk::sub(pk::make_v(S.r[0], S.r[1]), C01), d23 = pk::sub(pk::make_v(S.r[2], S.r[3]), C23);
     const pk::f2 rh01 = pk::fma_slo(c.eHF, d01, C01), rh23 = pk::fma_slo(c.eHF, d23, C23);  // rotor speeds at t + h/2
@@ -272,9 +277,8 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
     S.r[0] = rf01.x; S.r[1] = rf01.y; S.r[2] = rf23.x; S.r[3] = rf23.y;
     u0.aT2 = uf.U0.x; u0.tx = uf.U0.y; u0.ty = uf.Utz.x; u0.tz = uf.Utz.y;
 }
-#else
-#define DRONE_RK4_CONSTS(P)
-#define DRONE_RK4_EXTRA
+#endif  // DRONE_PK_RK4
+
 // one RK4 stage update over the 10 feedback components; the quaternion rows use the hq* steps
 #define DRONE_FOR_COMPONENTS(BODY)                                      \
     _Pragma("unroll") for (int i = 0; i < 3; i++) { BODY(v, i, h_) }    \
@@ -331,7 +335,18 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
     u0 = uf;
 }
 
-#endif  // DRONE_PK_RK4
+// all substeps of one env step, in the form the caller picked
+template <int TASK, bool PK>
+DRONE_FN void rk4_run(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u) {
+#if DRONE_PK_RK4
+    if constexpr (PK) {
+        const PkConsts c = pk_consts(P);  // once per env step, outside the substep loop
+        for (uint32_t k = 0; k < P.substeps; k++) rk4_substep_pk<TASK>(P, S, cmd, wind, u, c);
+        return;
+    }
+#endif
+    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, S, cmd, wind, u);
+}
 
 DRONE_FN float target_dist(const Lane& L) {
     const float dx = L.tgt[0] - L.s.p[0], dy = L.tgt[1] - L.s.p[1], dz = L.tgt[2] - L.s.p[2];
@@ -395,7 +410,7 @@ struct StepCtx {
 };
 
 // SPEC.md §5 steps 1–4: actions, wind, RK4, renormalise, clamp, tick.
-template <int TASK, bool CARRY = false>
+template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT>
 DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepCtx& ctx) {
     float a[4], cmd[4];
 #pragma unroll
@@ -423,8 +438,7 @@ DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], u
     }
 
     if (!CARRY) L.u = rotor_inputs(P, L.s.r);  // state fresh from HBM: nothing carried over from the previous step
-    DRONE_RK4_CONSTS(P)
-    for (uint32_t k = 0; k < P.substeps; k++) rk4_substep<TASK>(P, L.s, cmd, L.wind, L.u DRONE_RK4_EXTRA);
+    rk4_run<TASK, PK>(P, L.s, cmd, L.wind, L.u);
 
     {
         float* q = L.s.q;
@@ -543,10 +557,10 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
 }
 
 // Single-agent tasks: the whole of SPEC.md §5 steps 1–9.
-template <int TASK, bool CARRY = false>
+template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT>
 DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     StepCtx ctx;
-    lane_integrate<TASK, CARRY>(P, L, act, env, gstep, ctx);
+    lane_integrate<TASK, CARRY, PK>(P, L, act, env, gstep, ctx);
     lane_finish<TASK, CARRY>(P, L, env, ctx, 0.0f, out);
 }
 

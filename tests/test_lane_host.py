@@ -25,7 +25,7 @@ SO = os.path.join(HERE, "lane_host", "liblane_host.so")
 def lane(request):
     so = SO.replace(".so", f"_pk{request.param}.so")
     subprocess.run(["g++", "-O2", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-shared",
-                    f"-DDRONE_PK_RK4={request.param}", "-o", so, SRC], check=True)
+                    f"-DDRONE_PK_DEFAULT={request.param}", "-o", so, SRC], check=True)
     return C.CDLL(so)
 
 
