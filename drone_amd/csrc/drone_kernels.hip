@@ -901,6 +901,11 @@ inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // The packed-f32 RK4 form for the register-resident kernels: chosen per handle by the host (DeviceView::packed_rk4)
 inline bool use_packed(const DeviceView& v) { return DRONE_PK_RK4 && v.packed_rk4 != 0; }
 
+// hipGetLastError() reports the calling thread's last runtime error, whoever caused it (another library's call that
+// failed benignly, a query that returned not-ready). Drop anything stale first so that what a launch_* returns is
+// the launch's own status.
+inline void drop_stale_error() { (void)hipGetLastError(); }
+
 }  // namespace
 
 hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
