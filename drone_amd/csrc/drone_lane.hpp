@@ -15,8 +15,8 @@
 
 // The RK4 substep exists twice: scalar, and in two-wide f32 instructions with hand-placed modifiers (drone_pk.hpp).
 // Same results bit for bit (same expression trees). Which one runs is a template argument (PK) that the kernels choose
-// at launch: packed wins where a SIMD holds one or two waves (65 536 envs: fused rollout -8.6 %, step_many -5.8 %) and
-// loses once the chip is full (2^20 envs: rollout +8.9 %) — profiles/r03_ab/ab_pk_*.txt.
+// at launch: packed wins where a SIMD holds one wave (65 536 envs: fused rollout -8.8 %, step_many -3.9 %) and loses
+// from two waves per SIMD on (131 072 envs: +3...4 %; 2^20 envs: rollout +11 %) — profiles/r03_ab/ab_pk_*.txt.
 // DRONE_PK_RK4=0 compiles the packed form out (it needs the constants in SGPRs: not with the LDS-staged constants variant).
 // DRONE_PK_DEFAULT: what PK defaults to where the caller does not say (the host test harness builds once with each).
 #ifndef DRONE_PK_RK4

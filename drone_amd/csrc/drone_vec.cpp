@@ -596,11 +596,13 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         const char* o = getenv("DRONE_SWEEP_ORDER");
         v->dv.order = (o && *o) ? (uint32_t)atoi(o) : (touched <= ((size_t)400 << 20) ? 1u : touched <= ((size_t)768 << 20) ? 0u : 6u);
     }
-    {   // Packed-f32 RK4 in the register-resident kernels (fused rollout, step_many): wins while a SIMD holds at most two
-        // waves (<= 131 072 envs on the 1024 SIMDs: rollout -8.6 %, step_many -5.8 % at 65 536), loses on a full chip
-        // (+8.9 % on the rollout at 2^20) — profiles/r03_ab/ab_pk_*.txt. DRONE_PACKED_RK4=0/1 forces it.
+    {   // Packed-f32 RK4 in the register-resident kernels (fused rollout, step_many): wins only while a SIMD holds ONE
+        // wave (<= 65 536 envs on the 1024 SIMDs: rollout -8.8 %, step_many -3.9 %; waypoint / race -3...4 %), where the
+        // issue rate of one wave is the limit and a packed instruction costs 1.1x a scalar one for two results. With two
+        // waves per SIMD it already loses (131 072 envs: +3.3 % / +3.9 %), on a full chip clearly (2^20: rollout +11 %) —
+        // profiles/r03_ab/ab_pk_*.txt. DRONE_PACKED_RK4=0/1 forces it.
         const char* e = getenv("DRONE_PACKED_RK4");
-        v->dv.packed_rk4 = (e && *e) ? (atoi(e) != 0) : (v->n_pad <= 131072u);
+        v->dv.packed_rk4 = (e && *e) ? (atoi(e) != 0) : (v->n_pad <= 65536u);
     }
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
