@@ -241,6 +241,9 @@ int main(int argc, char** argv) {
     if (o.task < 0 || o.task > 3) { fprintf(stderr, "unknown task %d\n", o.task); return 2; }
     if (o.task == DRONE_TASK_SWARM && (o.total % (8 * o.gpus))) { fprintf(stderr, "swarm task: --envs must be a multiple of 8 x --gpus\n"); return 2; }
 
+    /* One node by construction (one process per local GPU): let RCCL's bootstrap use the loopback interface unless the
+     * user chose one — containers without a resolvable hostname or a routable interface otherwise stall it. */
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
     /* shared page + fork BEFORE any HIP call: a forked child of a process that initialised the GPU is not usable */
     Shared* sh = (Shared*)mmap(NULL, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (sh == MAP_FAILED) { perror("mmap"); return 1; }
