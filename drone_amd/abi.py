@@ -90,6 +90,7 @@ SYMBOLS = {
     "drone_config_default": (None, [C.POINTER(DroneConfig), C.c_int]),
     "drone_obs_dim": (C.c_int, [C.c_int]),
     "drone_vec_host_transport": (C.c_int, [_P]),
+    "drone_vec_bytes_per_env_step": (C.c_int, [_P]),
     "drone_device_count": (C.c_int, []),
     "drone_vec_init": (_P, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(DroneConfig)]),
     "drone_vec_reset": (None, [_P, C.c_uint64]),

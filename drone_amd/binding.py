@@ -277,6 +277,11 @@ class DroneVec:
         return self._f["drone_vec_gstep"](self._h)
 
     @property
+    def bytes_per_env_step(self):
+        """Algorithmic HBM bytes per env-step of the per-step kernel for this handle (task + state layout)."""
+        return self._f["drone_vec_bytes_per_env_step"](self._h)
+
+    @property
     def host_transport(self):
         """'zero-copy' (the kernel reads / writes the pinned host buffers over PCIe), 'mirror' (device mirrors +
         copies), or None for device buffers."""

@@ -18,6 +18,7 @@ struct DeviceView {
     uint32_t stride;     // float4 elements between the two cold planes (>= n_pad)
     uint32_t order;      // sweep order of the step kernel's workgroups: bit 0 one contiguous eighth per XCD, bit 1 reverse on odd steps, bit 2 non-temporal action loads (drone_kernels.hip my_chunk)
     uint32_t line_complete; // 1: rare per-lane plane updates go out as whole 128-B lines (working set beyond the Infinity Cache)
+    uint32_t derived_target; // 1: derived-target layout (hover / swarm): five planes per tile, no target plane, episode in P4 (drone_params.hpp)
     uint32_t packed_rk4; // 1: the fused rollout / step_many kernels run the RK4 substep in packed f32 instructions (small shards: one wave per SIMD)
     const uint32_t* kp;  // KParams in HBM (kParamWords words) — read only by the LDS-staging build
     const KParams* kp_host; // the same block in host memory (for launch-time by-value passing)

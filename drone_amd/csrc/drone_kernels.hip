@@ -183,15 +183,16 @@ struct RawLane {
 // No branches in here: the wait-count pass merges the outstanding-load state of all paths into a join and would
 // make the consumer of the CURRENT chunk wait for the prefetched one too. `ia` is the action row to read, already
 // clamped into the buffer by the caller (lanes >= n read the last row and never store anything).
-template <int TASK, bool STREAM>
+// DT: the derived-target layout (drone_params.hpp): five planes per tile, no target plane to read.
+template <int TASK, bool STREAM, bool DT>
 __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawLane<TASK>& R) {
-    R.a = pl[hot_index(hot_planes(TASK), kP0, i, np)];
-    R.b = pl[hot_index(hot_planes(TASK), kP1, i, np)];
-    R.c = pl[hot_index(hot_planes(TASK), kP2, i, np)];
-    R.d = pl[hot_index(hot_planes(TASK), kP3, i, np)];
-    R.e = pl[hot_index(hot_planes(TASK), kP4, i, np)];
-    R.t = pl[hot_index(hot_planes(TASK), kPT, i, np)];
-    if (has_aux_plane<TASK>()) R.w = pl[hot_index(hot_planes(TASK), kPW, i, np)];
+    R.a = pl[hot_index(hot_planes(TASK, DT), kP0, i, np)];
+    R.b = pl[hot_index(hot_planes(TASK, DT), kP1, i, np)];
+    R.c = pl[hot_index(hot_planes(TASK, DT), kP2, i, np)];
+    R.d = pl[hot_index(hot_planes(TASK, DT), kP3, i, np)];
+    R.e = pl[hot_index(hot_planes(TASK, DT), kP4, i, np)];
+    if (!DT) R.t = pl[hot_index(hot_planes(TASK, DT), kPT, i, np)];
+    if (has_aux_plane<TASK>()) R.w = pl[hot_index(hot_planes(TASK, DT), kPW, i, np)];
     // Non-temporal only where nothing is cached anyway (STREAM: the host picks that instantiation by footprint: -2 % at
     // 2^22 envs, but +19 % at 2^20 and +7 % at 131 072, where the hint pushes the rows out of the caches that serve them).
     if (STREAM) {  // compile time: a run-time branch here would make the wait-count pass drain all loads at the join
@@ -202,15 +203,31 @@ __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const fl
     }
 }
 
-template <int TASK>
-__device__ __forceinline__ void unpack_lane(const RawLane<TASK>& R, Lane& L, float (&act)[4]) {
-    const float4 &a = R.a, &b = R.b, &c = R.c, &d = R.d, &e = R.e, &t = R.t;
+// the words of P4 and PT that are not floats: (tick, score_count, episode) and the target, for either layout
+__device__ __forceinline__ void unpack_counters(const KParams& P, bool dt, const float4& e, const float4& t, uint32_t env, Lane& L) {
+    if (dt) {
+        const uint32_t ts = f2u(e.z);
+        L.tick = ts & 0xFFFFu;
+        L.score_count = ts >> 16;
+        L.episode = f2u(e.w);
+        derive_target(P, env, L.episode, L.tgt);
+    } else {
+        L.tick = f2u(e.z);
+        L.score_count = f2u(e.w);
+        L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z;
+        L.episode = f2u(t.w);
+    }
+}
+
+template <int TASK, bool DT>
+__device__ __forceinline__ void unpack_lane(const KParams& P, const RawLane<TASK>& R, uint32_t env, Lane& L, float (&act)[4]) {
+    const float4 &a = R.a, &b = R.b, &c = R.c, &d = R.d, &e = R.e;
     L.s.p[0] = a.x; L.s.p[1] = a.y; L.s.p[2] = a.z; L.s.v[0] = a.w;
     L.s.v[1] = b.x; L.s.v[2] = b.y; L.s.q[0] = b.z; L.s.q[1] = b.w;
     L.s.q[2] = c.x; L.s.q[3] = c.y; L.s.o[0] = c.z; L.s.o[1] = c.w;
     L.s.o[2] = d.x; L.s.r[0] = d.y; L.s.r[1] = d.z; L.s.r[2] = d.w;
-    L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
-    L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
+    L.s.r[3] = e.x; L.ep_return = e.y;
+    unpack_counters(P, DT, e, R.t, env, L);
     if (has_aux_plane<TASK>()) {
         L.wind[0] = R.w.x; L.wind[1] = R.w.y; L.wind[2] = R.w.z;
     } else {
@@ -219,38 +236,47 @@ __device__ __forceinline__ void unpack_lane(const RawLane<TASK>& R, Lane& L, flo
     act[0] = R.act.x; act[1] = R.act.y; act[2] = R.act.z; act[3] = R.act.w;
 }
 
+// `dt` is launch-uniform here (the register-resident kernels load and store the state once per launch: a branch costs nothing)
 template <int TASK>
-__device__ __forceinline__ void load_lane(const float4* __restrict__ pl, uint32_t np, uint32_t i, Lane& L) {
-    const float4 a = pl[hot_index(hot_planes(TASK), kP0, i, np)];
-    const float4 b = pl[hot_index(hot_planes(TASK), kP1, i, np)];
-    const float4 c = pl[hot_index(hot_planes(TASK), kP2, i, np)];
-    const float4 d = pl[hot_index(hot_planes(TASK), kP3, i, np)];
-    const float4 e = pl[hot_index(hot_planes(TASK), kP4, i, np)];
-    const float4 t = pl[hot_index(hot_planes(TASK), kPT, i, np)];
+__device__ __forceinline__ void load_lane(const KParams& P, const float4* __restrict__ pl, uint32_t np, uint32_t i, bool dt, Lane& L) {
+    const uint32_t nph = hot_planes(TASK, dt);
+    const float4 a = pl[hot_index(nph, kP0, i, np)];
+    const float4 b = pl[hot_index(nph, kP1, i, np)];
+    const float4 c = pl[hot_index(nph, kP2, i, np)];
+    const float4 d = pl[hot_index(nph, kP3, i, np)];
+    const float4 e = pl[hot_index(nph, kP4, i, np)];
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!dt) t = pl[hot_index(nph, kPT, i, np)];
     L.s.p[0] = a.x; L.s.p[1] = a.y; L.s.p[2] = a.z; L.s.v[0] = a.w;
     L.s.v[1] = b.x; L.s.v[2] = b.y; L.s.q[0] = b.z; L.s.q[1] = b.w;
     L.s.q[2] = c.x; L.s.q[3] = c.y; L.s.o[0] = c.z; L.s.o[1] = c.w;
     L.s.o[2] = d.x; L.s.r[0] = d.y; L.s.r[1] = d.z; L.s.r[2] = d.w;
-    L.s.r[3] = e.x; L.ep_return = e.y; L.tick = f2u(e.z); L.score_count = f2u(e.w);
-    L.tgt[0] = t.x; L.tgt[1] = t.y; L.tgt[2] = t.z; L.episode = f2u(t.w);
+    L.s.r[3] = e.x; L.ep_return = e.y;
+    unpack_counters(P, dt, e, t, P.env_offset + i, L);
     if (has_aux_plane<TASK>()) {
-        const float4 w = pl[hot_index(hot_planes(TASK), kPW, i, np)];
+        const float4 w = pl[hot_index(nph, kPW, i, np)];
         L.wind[0] = w.x; L.wind[1] = w.y; L.wind[2] = w.z;
     } else {
         L.wind[0] = L.wind[1] = L.wind[2] = 0.0f;
     }
 }
 
+// `dt`: a template constant in the per-step kernel (no branch may surround its stores), launch-uniform elsewhere
 template <int TASK>
-__device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np, uint32_t i, const Lane& L, bool target_changed) {
-    state_store(&pl[hot_index(hot_planes(TASK), kP0, i, np)], make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]));
-    state_store(&pl[hot_index(hot_planes(TASK), kP1, i, np)], make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]));
-    state_store(&pl[hot_index(hot_planes(TASK), kP2, i, np)], make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]));
-    state_store(&pl[hot_index(hot_planes(TASK), kP3, i, np)], make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]));
-    state_store(&pl[hot_index(hot_planes(TASK), kP4, i, np)], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
-    if (target_changed && !DRONE_EXP_NO_PT) pl[hot_index(hot_planes(TASK), kPT, i, np)] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
+__device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np, uint32_t i, const Lane& L, bool target_changed, bool dt) {
+    const uint32_t nph = hot_planes(TASK, dt);
+    state_store(&pl[hot_index(nph, kP0, i, np)], make_float4(L.s.p[0], L.s.p[1], L.s.p[2], L.s.v[0]));
+    state_store(&pl[hot_index(nph, kP1, i, np)], make_float4(L.s.v[1], L.s.v[2], L.s.q[0], L.s.q[1]));
+    state_store(&pl[hot_index(nph, kP2, i, np)], make_float4(L.s.q[2], L.s.q[3], L.s.o[0], L.s.o[1]));
+    state_store(&pl[hot_index(nph, kP3, i, np)], make_float4(L.s.o[2], L.s.r[0], L.s.r[1], L.s.r[2]));
+    if (dt) {  // the episode counter lives here; tick and score_count share a word (both <= horizon <= 65 535); no target plane
+        state_store(&pl[hot_index(nph, kP4, i, np)], make_float4(L.s.r[3], L.ep_return, u2f(L.tick | (L.score_count << 16)), u2f(L.episode)));
+    } else {
+        state_store(&pl[hot_index(nph, kP4, i, np)], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
+        if (target_changed && !DRONE_EXP_NO_PT) pl[hot_index(nph, kPT, i, np)] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
+    }
     // wind changes every step; a gate normal only together with its centre
-    if (TASK == DRONE_TASK_WAYPOINT || (TASK == DRONE_TASK_RACE && target_changed)) pl[hot_index(hot_planes(TASK), kPW, i, np)] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
+    if (TASK == DRONE_TASK_WAYPOINT || (TASK == DRONE_TASK_RACE && target_changed)) pl[hot_index(nph, kPW, i, np)] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
 }
 
 // per-env log sums: touched only when an episode ended
@@ -470,7 +496,7 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep) {
 // =====================================================================
 // per-step kernel (SPEC.md §5): configs 1–4
 // =====================================================================
-template <int TASK, bool COMPACT, bool STREAM = false>
+template <int TASK, bool COMPACT, bool STREAM, bool DT>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -488,7 +514,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
 #endif
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
-    load_raw<TASK, STREAM>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
+    load_raw<TASK, STREAM, DT>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
 #pragma unroll
     for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
@@ -498,13 +524,13 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         const bool more = t + 1 < DRONE_STEP_TILES && block_base + kBlock < n_pad;  // workgroup-uniform
         if (t + 1 < DRONE_STEP_TILES) {  // compile-time: the next chunk's loads are in flight while this one computes
             const uint32_t j = min(i + kBlock, n_pad - kBlock + threadIdx.x);  // past the end: this chunk again (unused)
-            load_raw<TASK, STREAM>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
+            load_raw<TASK, STREAM, DT>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
         }
 
         Lane L;
         float act[4];
         DRONE_STAMP(1);  // loads issued
-        unpack_lane<TASK>(cur, L, act);
+        unpack_lane<TASK, DT>(P, cur, P.env_offset + i, L, act);
 #if DRONE_STAMPS
         asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.r[3]), "v"(L.tgt[0]), "v"(act[0]));  // everything has landed
 #endif
@@ -527,13 +553,13 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         // envs; only the caller's buffers are exactly n long, and there the padding lanes' reward goes to a sink.
         const bool ended = !DRONE_EXP_NO_LOG && (out.oob || out.trunc);  // padding lanes included: their log slots exist too
         const bool log_lane = lane_bit(whole_lines(__ballot(ended), a.v.line_complete));   // this lane's log slots share a line with an ended episode's
-        const bool tgt_lane = lane_bit(whole_lines(__ballot(out.target_changed), a.v.line_complete));
+        const bool tgt_lane = !DT && lane_bit(whole_lines(__ballot(out.target_changed), a.v.line_complete));
         float4 l0, l1;
         if (log_lane) {
             l0 = a.v.cold[i];
             l1 = a.v.cold[np + i];
         }
-        store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, tgt_lane);
+        store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, tgt_lane, DT);
         out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], out.reward);
         DRONE_STAMP(4);  // state stores issued
 
@@ -597,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     Lane L;
     L.episode = 0u;
     lane_reset<TASK>(P, L, P.env_offset + i);
-    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, true);  // every plane of this task's tile (the wind plane starts at the zeros of the allocation's memset)
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, true, a.v.derived_target != 0);  // every plane of this task's tile (the wind plane starts at the zeros of the allocation's memset)
     a.v.cold[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.v.cold[np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n) a.v.rew[i] = 0.0f;
@@ -634,7 +660,8 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
     Lane L;
-    load_lane<TASK>(a.v.planes, a.v.n_pad, i, L);
+    const bool dt = a.v.derived_target != 0;
+    load_lane<TASK>(P, a.v.planes, a.v.n_pad, i, dt, L);
     L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
@@ -652,7 +679,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         if (out.oob || out.trunc) fold_log(l0, l1, out);
     }
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
-    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)));
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)), dt);
     out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], rsum);
     if (lane_bit(whole_lines(__ballot(any_term || any_trunc), a.v.line_complete))) {
         a.v.cold[i] = l0;
@@ -820,14 +847,15 @@ __global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m)
     const uint32_t block_base = my_chunk(a.v.order & 1u, 0u) * kBlock;
     const uint32_t i = block_base + threadIdx.x;
     Lane L;
-    load_lane<TASK>(a.v.planes, a.v.n_pad, i, L);
+    const bool dt = a.v.derived_target != 0;
+    load_lane<TASK>(P, a.v.planes, a.v.n_pad, i, dt, L);
     L.u = rotor_inputs(P, L.s.r);  // carried through the K steps (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     bool any_target = false, any_end = false;
     if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true, PK>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
     else many_loop<TASK, COMPACT, POLICY, false, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard (one workgroup: scalar form, less code)
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
-    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)));
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)), dt);
     if (lane_bit(whole_lines(__ballot(any_end), a.v.line_complete))) {
         a.v.cold[i] = l0;
         a.v.cold[np + i] = l1;
@@ -925,15 +953,18 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
     const bool compact = v.done_ids != nullptr;
     const bool stream = (v.order & 4u) != 0 || DRONE_NT_ACTION_LOADS;  // non-temporal action loads: HBM-only footprints
-#define DRONE_LAUNCH_STEP(T)                                                                 \
+#define DRONE_LAUNCH_STEP2(T, D)                                                             \
     do {                                                                                     \
-        if (compact) { if (stream) drone_step_kernel<T, true, true><<<g, b, 0, s>>>(a); else drone_step_kernel<T, true, false><<<g, b, 0, s>>>(a); } \
-        else { if (stream) drone_step_kernel<T, false, true><<<g, b, 0, s>>>(a); else drone_step_kernel<T, false, false><<<g, b, 0, s>>>(a); }    \
+        if (compact) { if (stream) drone_step_kernel<T, true, true, D><<<g, b, 0, s>>>(a); else drone_step_kernel<T, true, false, D><<<g, b, 0, s>>>(a); } \
+        else { if (stream) drone_step_kernel<T, false, true, D><<<g, b, 0, s>>>(a); else drone_step_kernel<T, false, false, D><<<g, b, 0, s>>>(a); }    \
     } while (0)
-    if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_STEP(DRONE_TASK_HOVER);
-    else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_STEP(DRONE_TASK_SWARM);
+#define DRONE_LAUNCH_STEP(T) DRONE_LAUNCH_STEP2(T, false)
+    const bool dt = v.derived_target != 0;
+    if (task == DRONE_TASK_HOVER) { if (dt) DRONE_LAUNCH_STEP2(DRONE_TASK_HOVER, true); else DRONE_LAUNCH_STEP(DRONE_TASK_HOVER); }
+    else if (task == DRONE_TASK_SWARM) { if (dt) DRONE_LAUNCH_STEP2(DRONE_TASK_SWARM, true); else DRONE_LAUNCH_STEP(DRONE_TASK_SWARM); }
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_STEP(DRONE_TASK_RACE);
     else DRONE_LAUNCH_STEP(DRONE_TASK_WAYPOINT);
+#undef DRONE_LAUNCH_STEP2
 #undef DRONE_LAUNCH_STEP
     return hipGetLastError();
 }

@@ -35,7 +35,7 @@ enum Plane : int {
     kP2 = 2,    // q.y q.z om.x om.y
     kP3 = 3,    // om.z rpm0 rpm1 rpm2
     kP4 = 4,    // rpm3 ep_return tick(u32) score_count(u32)
-    kPT = 5,    // target.x target.y target.z episode(u32)   — written only when it changes
+    kPT = 5,    // target.x target.y target.z episode(u32)   — written only when it changes; ABSENT in the derived-target layout
     kPW = 6,    // aux: wind.xyz (task 1) / gate normal (task 3)  — tasks 1 and 3 only
     kL0 = 7,    // perf_sum score_sum ret_sum len_sum        — touched only when an episode ends
     kL1 = 8,    // n_sum oob_sum (pad) (pad)
@@ -72,7 +72,13 @@ struct KParams {
 };
 constexpr uint32_t kTile = 64;  // drones per state tile = one wavefront
 // planes per hot tile: the aux plane (wind / gate normal) exists only for the tasks that use it
-DRONE_FN constexpr uint32_t hot_planes(int task) { return (task == DRONE_TASK_WAYPOINT || task == DRONE_TASK_RACE) ? 7u : 6u; }
+// Derived-target layout (`dt`; hover and swarm tasks only): their target is a pure function of (reset key, env, episode) —
+// SPEC.md section 6 draws it at reset and nothing else writes it — so the target plane need not exist: the episode
+// counter moves into P4 (tick and score_count share one word, 16 bits each: both are <= horizon <= 65 535) and the
+// kernels re-derive the target from three hashes instead of reading 16 bytes per env and step (278 -> 262 B for hover).
+// Chosen per handle by the host where the step is HBM-bound (DeviceView::derived_target).
+DRONE_FN constexpr uint32_t hot_planes(int task, bool dt = false) { return (task == DRONE_TASK_WAYPOINT || task == DRONE_TASK_RACE) ? 7u : dt ? 5u : 6u; }
+DRONE_FN constexpr bool task_has_derived_target(int task) { return task == DRONE_TASK_HOVER || task == DRONE_TASK_SWARM; }
 #ifndef DRONE_TILED_STATE  // 0: plain planes [plane][n_pad] (the round-1 layout; kept for A/B at equal placement)
 #define DRONE_TILED_STATE 1
 #endif
@@ -109,6 +115,16 @@ DRONE_FN float sym(uint32_t u) { return __builtin_fmaf((float)(u >> 8), 1.192092
 DRONE_FN float s16(uint32_t h) { return __builtin_fmaf((float)h, 3.0517578125e-5f, -1.0f); }
 // j-th 16-bit half of a run of 32-bit draws, low half first
 DRONE_FN uint32_t half16(const uint32_t* u, uint32_t j) { return (j & 1u) ? (u[j >> 1] >> 16) : (u[j >> 1] & 0xFFFFu); }
+
+// SPEC.md §6, the target alone: what lane_reset draws for episode `episode` of env `env` (halves 3, 4, 5 of the five
+// reset draws). Used by the derived-target layout, which stores no target plane for the hover and swarm tasks.
+DRONE_FN void derive_target(const KParams& P, uint32_t env, uint32_t episode, float (&tgt)[3]) {
+    const uint32_t b = rng_base(P.key_reset, env, episode);
+    const uint32_t u1 = rng_draw(b, 1u), u2 = rng_draw(b, 2u);
+    tgt[0] = P.target_extent * s16(u1 >> 16);
+    tgt[1] = P.target_extent * s16(u2 & 0xFFFFu);
+    tgt[2] = P.target_extent * s16(u2 >> 16);
+}
 
 inline uint32_t stream_key(uint64_t seed, uint32_t stream) {
     return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) ^ (0x9E3779B9u * (stream + 1u))));

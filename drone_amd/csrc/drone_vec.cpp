@@ -492,6 +492,16 @@ int drone_device_count(void) {
     return n;
 }
 
+int drone_vec_bytes_per_env_step(const DroneVec* v) {
+    if (!v) return 0;
+    const int task = v->cfg.task;
+    const int aux = (task == DRONE_TASK_WAYPOINT || task == DRONE_TASK_RACE) ? 1 : 0, dt = v->dv.derived_target ? 1 : 0;
+    // read: planes (6 / 7, or 5 derived-target) + action row; written: planes but the target one (+ the wind plane every step for
+    // task 1; the gate normal of task 3 only per gate) + observation row + reward + 2 flag bytes
+    const int planes_read = 6 + aux - dt, planes_written = 5 + (task == DRONE_TASK_WAYPOINT ? 1 : 0);
+    return 16 * (planes_read + planes_written) + 16 + 4 * drone_obs_dim(task) + 4 + 2;
+}
+
 int drone_vec_host_transport(const DroneVec* v) { return !v ? -1 : !v->host_buffers ? -1 : v->zero_copy ? 1 : 0; }
 
 int drone_obs_dim(int task) { return (task == DRONE_TASK_SWARM || task == DRONE_TASK_RACE) ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
@@ -528,7 +538,18 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->own_stream = true;
     INIT_TRY(hipEventCreate(&v->ev0));
     INIT_TRY(hipEventCreate(&v->ev1));
-    const size_t hot_elems = (size_t)v->n_pad * hot_planes(cfg->task), cold_elems = (size_t)2 * v->stride;
+    {   // Derived-target layout (drone_params.hpp): hover / swarm handles whose step is HBM-bound drop the target plane
+        // (16 of hover's 278 bytes per env-step) and re-derive the target from three hashes per step. It needs tick
+        // and score_count in 16 bits each (horizon <= 65 535). Chosen by footprint like the other layout knobs
+        // (profiles/r03_ab/ab_dt_*.txt: it pays from ~2^18 envs on and costs VALU-bound small shards ~2 %);
+        // DRONE_DERIVED_TARGET=0/1 forces it (1 is ignored where the layout cannot represent the handle).
+        const bool can = task_has_derived_target(cfg->task) && cfg->horizon <= 65535;
+        const char* e = getenv("DRONE_DERIVED_TARGET");
+        const size_t per_step = (size_t)num_envs * 278u;
+        v->dv.derived_target = can && ((e && *e) ? (atoi(e) != 0) : (per_step >= ((size_t)64 << 20)));
+    }
+    const bool dt = v->dv.derived_target != 0;
+    const size_t hot_elems = (size_t)v->n_pad * hot_planes(cfg->task, dt), cold_elems = (size_t)2 * v->stride;
     INIT_TRY(hipMalloc((void**)&v->dv.planes, sizeof(float4) * hot_elems));
     INIT_TRY(hipMemsetAsync(v->dv.planes, 0, sizeof(float4) * hot_elems, v->stream));
     INIT_TRY(hipMalloc((void**)&v->dv.cold, sizeof(float4) * cold_elems));
@@ -587,7 +608,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // them: widen them to whole lines once a step touches more than twice its 256 MiB (measured cross-over between
         // 2^20 and 2^22 envs, profiles/r02_ab/). DRONE_LINE_COMPLETE=0/1 forces it.
         const char* e = getenv("DRONE_LINE_COMPLETE");
-        const size_t touched = n * (sizeof(float4) * (2 * hot_planes(cfg->task) - 1) + (size_t)drone_obs_dim(cfg->task) * 4 + 16 + 6);
+        const size_t touched = n * (sizeof(float4) * (dt ? 2 * hot_planes(cfg->task, true) : 2 * hot_planes(cfg->task) - 1) + (size_t)drone_obs_dim(cfg->task) * 4 + 16 + 6);
         v->dv.line_complete = (e && *e) ? (atoi(e) != 0) : (touched > ((size_t)512 << 20));
         // Sweep order of the step kernel, by the same footprint (DRONE_SWEEP_ORDER=0..7 forces it): up to ~1.5x the
         // Infinity Cache, one contiguous eighth per XCD (-2.7 % at 2^20 envs); beyond, one global round-robin sweep
@@ -927,7 +948,7 @@ bool image_copy(DroneVec* v, StateImage& im, bool to_device) {
 }
 
 bool image_fetch(DroneVec* v, int first, int count, StateImage& im) {
-    im.nph = hot_planes(v->cfg.task);
+    im.nph = hot_planes(v->cfg.task, v->dv.derived_target != 0);
     im.first = (uint32_t)first;
     im.tile0 = (uint32_t)first / kTile;
     im.ntiles = ((uint32_t)(first + count) + kTile - 1) / kTile - im.tile0;
@@ -950,10 +971,11 @@ int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) 
     StateImage im;
     if (!image_fetch(v, first, count, im)) return -1;
     auto u = [](float f) { uint32_t x; memcpy(&x, &f, 4); return x; };
-    const bool aux = im.nph == 7;
+    const bool aux = im.nph == 7, dt = v->dv.derived_target != 0;
     for (int k = 0; k < count; k++) {
         const uint32_t e = (uint32_t)(first + k);
-        const float4 a = im.at(kP0, e), b = im.at(kP1, e), c = im.at(kP2, e), d = im.at(kP3, e), ee = im.at(kP4, e), t = im.at(kPT, e);
+        const float4 a = im.at(kP0, e), b = im.at(kP1, e), c = im.at(kP2, e), d = im.at(kP3, e), ee = im.at(kP4, e);
+        const float4 t = dt ? make_float4(0.f, 0.f, 0.f, 0.f) : im.at(kPT, e);
         const float4 w = aux ? im.at(kPW, e) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 l0 = im.cold[k], l1 = im.cold[(size_t)count + k];
         DroneStateRow& r = rows[k];
@@ -961,8 +983,14 @@ int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) 
         r.vel[1] = b.x; r.vel[2] = b.y; r.quat[0] = b.z; r.quat[1] = b.w;
         r.quat[2] = c.x; r.quat[3] = c.y; r.omega[0] = c.z; r.omega[1] = c.w;
         r.omega[2] = d.x; r.rpm[0] = d.y; r.rpm[1] = d.z; r.rpm[2] = d.w;
-        r.rpm[3] = ee.x; r.ep_return = ee.y; r.tick = u(ee.z); r.score_count = u(ee.w);
-        r.target[0] = t.x; r.target[1] = t.y; r.target[2] = t.z; r.episode = u(t.w);
+        r.rpm[3] = ee.x; r.ep_return = ee.y;
+        if (dt) {  // derived-target layout: counters packed in P4, the target re-derived as the kernels do
+            r.tick = u(ee.z) & 0xFFFFu; r.score_count = u(ee.z) >> 16; r.episode = u(ee.w);
+            derive_target(v->kp, v->kp.env_offset + e, r.episode, r.target);
+        } else {
+            r.tick = u(ee.z); r.score_count = u(ee.w);
+            r.target[0] = t.x; r.target[1] = t.y; r.target[2] = t.z; r.episode = u(t.w);
+        }
         r.wind[0] = w.x; r.wind[1] = w.y; r.wind[2] = w.z;
         r.perf_sum = l0.x; r.score_sum = l0.y; r.ret_sum = l0.z; r.len_sum = l0.w;
         r.n_sum = l1.x; r.oob_sum = l1.y;
@@ -979,16 +1007,29 @@ int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int c
     StateImage im;
     if (!image_fetch(v, first, count, im)) return -1;
     auto f = [](uint32_t x) { float y; memcpy(&y, &x, 4); return y; };
-    const bool aux = im.nph == 7;
+    const bool aux = im.nph == 7, dt = v->dv.derived_target != 0;
     for (int k = 0; k < count; k++) {
         const uint32_t e = (uint32_t)(first + k);
         const DroneStateRow& r = rows[k];
+        if (dt) {  // this layout stores no target: the row's must be the one its (env, episode) implies, and the counters must fit
+            float want[3];
+            derive_target(v->kp, v->kp.env_offset + e, r.episode, want);
+            if (memcmp(want, r.target, sizeof(want)) != 0 || r.tick > 0xFFFFu || r.score_count > 0xFFFFu) {
+                set_err("set_state: env %u: the derived-target layout (hover / swarm, DRONE_DERIVED_TARGET) cannot hold a target other than the one "
+                        "SPEC.md section 6 draws for (env, episode), nor counters beyond 65535; create the handle with DRONE_DERIVED_TARGET=0 for free-form states", e);
+                return -1;
+            }
+        }
         im.at(kP0, e) = make_float4(r.pos[0], r.pos[1], r.pos[2], r.vel[0]);
         im.at(kP1, e) = make_float4(r.vel[1], r.vel[2], r.quat[0], r.quat[1]);
         im.at(kP2, e) = make_float4(r.quat[2], r.quat[3], r.omega[0], r.omega[1]);
         im.at(kP3, e) = make_float4(r.omega[2], r.rpm[0], r.rpm[1], r.rpm[2]);
-        im.at(kP4, e) = make_float4(r.rpm[3], r.ep_return, f(r.tick), f(r.score_count));
-        im.at(kPT, e) = make_float4(r.target[0], r.target[1], r.target[2], f(r.episode));
+        if (dt) {
+            im.at(kP4, e) = make_float4(r.rpm[3], r.ep_return, f(r.tick | (r.score_count << 16)), f(r.episode));
+        } else {
+            im.at(kP4, e) = make_float4(r.rpm[3], r.ep_return, f(r.tick), f(r.score_count));
+            im.at(kPT, e) = make_float4(r.target[0], r.target[1], r.target[2], f(r.episode));
+        }
         if (aux) im.at(kPW, e) = make_float4(r.wind[0], r.wind[1], r.wind[2], 0.0f);
         im.cold[k] = make_float4(r.perf_sum, r.score_sum, r.ret_sum, r.len_sum);
         im.cold[(size_t)count + k] = make_float4(r.n_sum, r.oob_sum, 0.0f, 0.0f);

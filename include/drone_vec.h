@@ -100,6 +100,10 @@ void drone_config_default(DroneConfig* cfg, int task);
 /* HIP devices visible to this process (0 if none / HIP unusable); a multi-process host maps ranks onto them. */
 int drone_device_count(void);
 
+/* Algorithmic HBM bytes the per-step kernel moves per env and step for THIS handle (task and state layout: hover 278, or
+ * 262 when the handle uses the derived-target layout; waypoint / race 310; swarm 294 / 278) — what bench.py's roofline uses. */
+int drone_vec_bytes_per_env_step(const DroneVec* v);
+
 /* 1 if host-buffer steps of this handle run zero-copy (kernel reads / writes the caller's pinned buffers over PCIe),
  * 0 if they go through device mirrors and copies; -1 for device-buffer handles. */
 int drone_vec_host_transport(const DroneVec* v);
