@@ -541,12 +541,13 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     {   // Derived-target layout (drone_params.hpp): hover / swarm handles whose step is HBM-bound drop the target plane
         // (16 of hover's 278 bytes per env-step) and re-derive the target from three hashes per step. It needs tick
         // and score_count in 16 bits each (horizon <= 65 535). Chosen by footprint like the other layout knobs
-        // (profiles/r03_ab/ab_dt_*.txt: it pays from ~2^18 envs on and costs VALU-bound small shards ~2 %);
+        // (profiles/r03_ab/ab_dt_*.txt: -4.4 % at 2^19 envs, -5.2 % at 2^20, -6.4 % at 2^21, -4.7 % at 2^22; neutral at
+        // 2^18 and +1.4 % at 131 072, where the step is bound by one or two waves per SIMD issuing VALU, not by bytes);
         // DRONE_DERIVED_TARGET=0/1 forces it (1 is ignored where the layout cannot represent the handle).
         const bool can = task_has_derived_target(cfg->task) && cfg->horizon <= 65535;
         const char* e = getenv("DRONE_DERIVED_TARGET");
         const size_t per_step = (size_t)num_envs * 278u;
-        v->dv.derived_target = can && ((e && *e) ? (atoi(e) != 0) : (per_step >= ((size_t)64 << 20)));
+        v->dv.derived_target = can && ((e && *e) ? (atoi(e) != 0) : (per_step >= ((size_t)100 << 20)));
     }
     const bool dt = v->dv.derived_target != 0;
     const size_t hot_elems = (size_t)v->n_pad * hot_planes(cfg->task, dt), cold_elems = (size_t)2 * v->stride;
