@@ -98,6 +98,9 @@
 #define DRONE_STAMP(k) do {} while (0)
 #endif
 
+#ifndef DRONE_CARRY_ROTOR  // 1: the register-resident kernels carry the rotor inputs from step to step (Lane::u); 0: recompute them every step (A/B only)
+#define DRONE_CARRY_ROTOR 1
+#endif
 #ifndef DRONE_ROLLOUT_MIN_WAVES  // __launch_bounds__ 2nd argument of the fused rollout kernel; 0 = unset
 #define DRONE_ROLLOUT_MIN_WAVES 0
 #endif
@@ -671,7 +674,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK, true, PK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -773,7 +776,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     if (POLICY) random_action(P.key_action, env, gstep, act);
     else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
     StepOut out;
-    step_any<TASK, true, PK>(P, L, tile, act, env, gstep, out);
+    step_any<TASK, DRONE_CARRY_ROTOR != 0, PK>(P, L, tile, act, env, gstep, out);
     const bool ended = out.oob || out.trunc;
     any_target |= out.target_changed;
     any_end |= ended;
