@@ -670,6 +670,9 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     const uint32_t env = P.env_offset + i;
     float rsum = 0.0f;
     bool any_term = false, any_trunc = false, any_target = false;
+#if DRONE_STAMPS  // diagnostic build: the shader clock this kernel holds = delta s_memtime / delta s_memrealtime x 100 MHz (tools/rollout_clock.py)
+    const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t t = 0; t < horizon; t++) {
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
@@ -681,6 +684,13 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         any_target |= out.target_changed;
         if (out.oob || out.trunc) fold_log(l0, l1, out);
     }
+#if DRONE_STAMPS
+    asm volatile("" ::"v"(rsum), "v"(L.s.p[0]));
+    if (a.v.stamps && (threadIdx.x & (kWave - 1)) == 0) {
+        unsigned long long* row = a.v.stamps + (size_t)(i / kWave) * kStampSlots;
+        row[0] = ck0; row[1] = __builtin_amdgcn_s_memtime(); row[8] = rt0; row[9] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
     store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)), dt);
     out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], rsum);
