@@ -67,6 +67,9 @@
 #define DRONE_STEP_TILES 1
 #endif
 
+#ifndef DRONE_STEP_WAVE_OUTPUTS  // 1: full workgroups of the per-step kernel write their outputs per WAVE (write_outputs_wave: no LDS masks, no workgroup barrier, 64-byte flag pieces) like the K-steps kernel; 0: per workgroup (256-byte flag pieces behind one barrier)
+#define DRONE_STEP_WAVE_OUTPUTS 0
+#endif
 #ifndef DRONE_LOG_FOLD_LATE  // 1: the log-plane read-modify-write of an ended episode completes at the very end of the chunk; 0: right after the state stores
 #define DRONE_LOG_FOLD_LATE 1
 #endif
@@ -389,6 +392,43 @@ __device__ __forceinline__ void write_outputs(Shared& sh, const DeviceView& v, u
     }
 }
 
+// A FULL wave's outputs of one step, on ONE static path with a fixed number of vector-memory operations and no
+// workgroup barrier: the wait-count pass keeps, at every join, the most conservative outstanding-store count of the
+// joined paths, and the exec-skip branch the compiler puts around any divergent store is such a path — a single
+// guarded store in the loop body makes the wait for the prefetched action row drain the previous step's stores.
+// So: every lane stores, always. Observation rows as in write_outputs (wave-private LDS transpose, OBSV x 1 KiB).
+// Flag bytes per wave instead of per workgroup (no LDS masks, no barrier): the wave's 64 + 64 bytes leave as eight
+// 16-byte pieces; all 64 lanes take part, lanes l and l + 8k writing the same bytes to the same address.
+template <int OBSV>
+__device__ __forceinline__ void write_outputs_wave(float4* tile, float* obs_wave, unsigned char* term_wave, unsigned char* trunc_wave, bool flags16,
+                                                   const float (&o)[DRONE_OBS_DIM_MAX], bool term, bool trunc) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t m_term = __ballot(term);
+    const uint64_t m_trunc = __ballot(trunc);
+#pragma unroll
+    for (int k = 0; k < OBSV; k++) tile[lane * OBSV + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4* dst = reinterpret_cast<float4*>(obs_wave);
+    float4 piece[OBSV];
+#pragma unroll
+    for (int k = 0; k < OBSV; k++) piece[k] = tile[k * kWave + lane];
+#pragma unroll
+    for (int k = 0; k < OBSV; k++) out_store(&dst[k * kWave + lane], piece[k]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads are done before the tile is written again
+    __builtin_amdgcn_wave_barrier();
+    if (flags16) {  // launch-uniform: both flag blocks and the env count are 16-byte multiples
+        const uint32_t which = (lane >> 2) & 1u, j = lane & 3u;
+        const uint32_t bits = (uint32_t)((which ? m_trunc : m_term) >> (j * 16u)) & 0xFFFFu;
+        const u4_t packed = {spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12)};
+        out_store(reinterpret_cast<u4_t*>(which ? trunc_wave : term_wave) + j, packed);
+    } else {
+        term_wave[lane] = term ? 1 : 0;
+        trunc_wave[lane] = trunc ? 1 : 0;
+    }
+}
+
 // SPEC.md §10: nearest neighbour among the lanes of this drone's swarm — the
 // A = P.agents consecutive lanes starting at lane & ~(A-1). Each lane parks its
 // position as one float4 in the wave's (otherwise idle) observation tile and
@@ -589,6 +629,13 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
         float o[DRONE_OBS_DIM_MAX];
         obs_any<TASK>(P, L, tile, o);
         DRONE_STAMP(5);  // observation math done
+#if DRONE_STEP_WAVE_OUTPUTS
+        if (block_base + kBlock <= n) {  // workgroup-uniform
+            const uint32_t wave_base = i - lane;
+            write_outputs_wave<obs_vec<TASK>()>(tile, a.v.obs + (size_t)wave_base * (4 * obs_vec<TASK>()), a.v.term + wave_base, a.v.trunc + wave_base,
+                                                (a.flags_aligned & 3u) == 3u, o, out.oob, out.trunc);
+        } else
+#endif
         write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base, (uint32_t)t & 1u);
         DRONE_STAMP(6);  // LDS transpose, barrier, observation / flag stores issued
 #if DRONE_LOG_FOLD_LATE
@@ -734,43 +781,6 @@ struct ManyArgs {
     uint32_t* done_count;  // [K], zeroed by the host before the launch
     uint32_t k_steps;
 };
-
-// A FULL wave's outputs of one step, on ONE static path with a fixed number of vector-memory operations and no
-// workgroup barrier: the wait-count pass keeps, at every join, the most conservative outstanding-store count of the
-// joined paths, and the exec-skip branch the compiler puts around any divergent store is such a path — a single
-// guarded store in the loop body makes the wait for the prefetched action row drain the previous step's stores.
-// So: every lane stores, always. Observation rows as in write_outputs (wave-private LDS transpose, OBSV x 1 KiB).
-// Flag bytes per wave instead of per workgroup (no LDS masks, no barrier): the wave's 64 + 64 bytes leave as eight
-// 16-byte pieces; all 64 lanes take part, lanes l and l + 8k writing the same bytes to the same address.
-template <int OBSV>
-__device__ __forceinline__ void write_outputs_wave(float4* tile, float* obs_wave, unsigned char* term_wave, unsigned char* trunc_wave, bool flags16,
-                                                   const float (&o)[DRONE_OBS_DIM_MAX], bool term, bool trunc) {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint64_t m_term = __ballot(term);
-    const uint64_t m_trunc = __ballot(trunc);
-#pragma unroll
-    for (int k = 0; k < OBSV; k++) tile[lane * OBSV + k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float4* dst = reinterpret_cast<float4*>(obs_wave);
-    float4 piece[OBSV];
-#pragma unroll
-    for (int k = 0; k < OBSV; k++) piece[k] = tile[k * kWave + lane];
-#pragma unroll
-    for (int k = 0; k < OBSV; k++) out_store(&dst[k * kWave + lane], piece[k]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads are done before the tile is written again
-    __builtin_amdgcn_wave_barrier();
-    if (flags16) {  // launch-uniform: both flag blocks and the env count are 16-byte multiples
-        const uint32_t which = (lane >> 2) & 1u, j = lane & 3u;
-        const uint32_t bits = (uint32_t)((which ? m_trunc : m_term) >> (j * 16u)) & 0xFFFFu;
-        const u4_t packed = {spread4(bits), spread4(bits >> 4), spread4(bits >> 8), spread4(bits >> 12)};
-        out_store(reinterpret_cast<u4_t*>(which ? trunc_wave : term_wave) + j, packed);
-    } else {
-        term_wave[lane] = term ? 1 : 0;
-        trunc_wave[lane] = trunc ? 1 : 0;
-    }
-}
 
 // one env step of the K: everything between "action row in registers" and "outputs of step k issued".
 // FULL: every lane of this workgroup is a real env (all but the last workgroup of a ragged shard).
