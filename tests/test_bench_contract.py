@@ -36,7 +36,10 @@ def test_bench_line_has_the_contract_fields(hip):
     assert str(1 << 23) in pts and ("frac" in pts[str(1 << 23)] or "skipped" in pts[str(1 << 23)])
     # round 3: every other single-GPU BASELINE workload timed in the same run, each with its own bytes
     cf = d["configs"]
-    assert set(cf) == {"configs[1]", "configs[2]/shard", "configs[3]"}
+    assert set(cf) == {"configs[0]", "configs[1]", "configs[2]/shard", "configs[3]"}
+    c0 = cf["configs[0]"]  # BASELINE's CPU plumbing case: 1024 envs on one host thread, and the same through the HIP path
+    assert c0["envs"] == 1024 and c0["cpu"]["threads"] == 1 and c0["cpu"]["env_steps_per_s"] > 1e6
+    assert c0["per_step"]["launch_us"] > 0 and c0["host_buffers"]["transport"] == "zero-copy" and c0["host_buffers"]["wall_us_per_step"] > 0
     for name, envs, task, nbytes in (("configs[1]", 65536, "hover", 278), ("configs[2]/shard", 131072, "hover", 278), ("configs[3]", 262144, "waypoint", 310)):
         c = cf[name]
         assert "skipped" not in c, c
