@@ -140,7 +140,9 @@ void drone_vec_rollout(DroneVec* v, int horizon);
  * neither read nor written. State stays in registers between the K steps: the dependent-launch boundary and the state
  * planes' HBM traffic are paid once per K steps (hover: 102 + 176 / K bytes per env-step instead of 278), which is what
  * small shards (one wave per SIMD, launch-boundary bound) need. Consumers: open-loop action segments, action repeat /
- * frame skip, a device-side policy. With compact_done=1 every step's done-id list is kept: drone_vec_done_list_at. */
+ * frame skip, a device-side policy. With compact_done=1 every step's done-id list is kept: drone_vec_done_list_at.
+ * Capturable into a hipGraph after drone_vec_enable_graph_capture (device buffers): make one call outside the capture
+ * first — it sizes the K-dependent storage, which needs a stream sync. */
 void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
                          unsigned char* terminals, unsigned char* truncations);
 

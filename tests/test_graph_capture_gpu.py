@@ -134,3 +134,40 @@ def test_host_buffers_refuse_graph_mode(hip):
     with pytest.raises(RuntimeError, match="device buffers"):
         h.enable_graph_capture(True)
     h.clear_status()
+
+
+def test_captured_step_many_replays(oracle, hip):
+    """drone_vec_step_many under torch.cuda.graph: K = 6 steps with the in-kernel policy and per-step done lists captured
+    ONCE (the counters in HBM, the done-count memset a graph node of its own), replayed 9 times = 54 oracle steps; the
+    blocks after the last replay hold that replay's six steps. Storage is grown by a first call outside the capture."""
+    import torch
+
+    n, seed, K, replays = 12000, 6, 6, 9
+    o, h = make_pair(oracle, hip, n, seed, 1, horizon=17, compact_done=1)
+    h.enable_graph_capture(True)
+    bufs = h.alloc_step_many(K)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        h.use_torch_stream()
+        h.step_many(bufs, policy=True)        # warm-up: sizes the per-step list storage (a sync, not capturable)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        h.use_torch_stream()
+        h.step_many(bufs, policy=True)
+    for _ in range(replays):
+        g.replay()
+    torch.cuda.synchronize()
+    assert h.gstep == K * (1 + replays)
+    last = None
+    for _ in range(1 + replays):
+        last = o.step_many(K, None)
+    obs, rew, term, trunc, done = last
+    assert_bits_equal(obs, bufs.observations, "observations of the last replay")
+    assert_bits_equal(rew, bufs.rewards, "rewards of the last replay")
+    assert_bits_equal(term, bufs.terminals, "terminals")
+    assert_bits_equal(trunc, bufs.truncations, "truncations")
+    for k in range(K):
+        assert_bits_equal(done[k], np.sort(h.done_list_at(k)), f"done ids of step {k} of the last replay")
+    assert_state_equal(o.get_state(), h.get_state(), "state after the replays")
