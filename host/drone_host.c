@@ -58,7 +58,7 @@ static double now_s(void) {
 }
 
 int main(int argc, char** argv) {
-    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0;
+    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0, many = 0;
     unsigned long long seed = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--envs")) envs = atoi(argv[i + 1]);
@@ -67,12 +67,14 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--rollout")) rollout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], NULL, 10);
         else if (!strcmp(argv[i], "--crc")) crc_mode = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--many")) many = atoi(argv[i + 1]); /* K > 0: step through drone_vec_step_many, K env steps per call */
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     if (task != DRONE_TASK_HOVER && task != DRONE_TASK_WAYPOINT && task != DRONE_TASK_SWARM && task != DRONE_TASK_RACE) {
         fprintf(stderr, "unknown task %d (0 hover, 1 waypoint, 2 swarm, 3 race)\n", task);
         return 2;
     }
+    if (many < 0 || many > 4096) { fprintf(stderr, "--many must be in [0, 4096]\n"); return 2; }
     if (envs <= 0 || steps <= 0 || rollout <= 0) { fprintf(stderr, "--envs, --steps and --rollout must be positive\n"); return 2; }
     const size_t obs_dim = (size_t)drone_obs_dim(task); /* 20, or 24 for the swarm and race tasks */
     float* obs = (float*)page_alloc(sizeof(float) * (size_t)envs * obs_dim);
@@ -91,10 +93,36 @@ int main(int argc, char** argv) {
     drone_vec_reset(v, seed);
     if (drone_vec_status(v)) { fprintf(stderr, "drone_vec_reset failed: %s\n", drone_vec_status_message(v)); return 1; }
 
+    /* K-major blocks for drone_vec_step_many: actions [K][N][4] in, observations [K][N][O] / rewards / flags [K][N] out */
+    float *m_act = NULL, *m_obs = NULL, *m_rew = NULL;
+    unsigned char *m_term = NULL, *m_trunc = NULL;
+    if (many > 0) {
+        const size_t kn = (size_t)many * (size_t)envs;
+        m_act = (float*)page_alloc(sizeof(float) * kn * DRONE_ACT_DIM);
+        m_obs = (float*)page_alloc(sizeof(float) * kn * obs_dim);
+        m_rew = (float*)page_alloc(sizeof(float) * kn);
+        m_term = (unsigned char*)page_alloc(kn);
+        m_trunc = (unsigned char*)page_alloc(kn);
+        if (!m_act || !m_obs || !m_rew || !m_term || !m_trunc) { fprintf(stderr, "out of memory\n"); return 1; }
+    }
+
     if (crc_mode) {
         uint32_t crc = 0;
         crc = crc32_update(crc, obs, sizeof(float) * (size_t)envs * obs_dim); /* the reset observations */
-        for (int t = 0; t < steps; t++) {
+        for (int t = 0; many > 0 && t < steps;) { /* the same CRC chain through K steps per call: step by step, obs / rew / term / trunc */
+            const int k_now = steps - t < many ? steps - t : many;
+            for (int k = 0; k < k_now; k++) drone_vec_fill_random_actions(v, m_act + (size_t)k * envs * DRONE_ACT_DIM, drone_vec_gstep(v) + (uint32_t)k);
+            drone_vec_step_many(v, k_now, m_act, m_obs, m_rew, m_term, m_trunc);
+            for (int k = 0; k < k_now; k++) {
+                const size_t r0 = (size_t)k * (size_t)envs;
+                crc = crc32_update(crc, m_obs + r0 * obs_dim, sizeof(float) * (size_t)envs * obs_dim);
+                crc = crc32_update(crc, m_rew + r0, sizeof(float) * (size_t)envs);
+                crc = crc32_update(crc, m_term + r0, (size_t)envs);
+                crc = crc32_update(crc, m_trunc + r0, (size_t)envs);
+            }
+            t += k_now;
+        }
+        for (int t = 0; many == 0 && t < steps; t++) {
             drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
             drone_vec_step(v);
             crc = crc32_update(crc, obs, sizeof(float) * (size_t)envs * obs_dim);
@@ -105,7 +133,7 @@ int main(int argc, char** argv) {
         if (drone_vec_status(v)) { fprintf(stderr, "step failed: %s\n", drone_vec_status_message(v)); return 1; }
         DroneLog lg;
         drone_vec_log(v, &lg);
-        printf("{\"mode\": \"crc\", \"task\": %d, \"envs\": %d, \"steps\": %d, \"crc32\": %u, \"episodes\": %.0f}\n", task, envs, steps, crc, lg.n);
+        printf("{\"mode\": \"crc\", \"task\": %d, \"envs\": %d, \"steps\": %d, \"steps_per_call\": %d, \"crc32\": %u, \"episodes\": %.0f}\n", task, envs, steps, many > 0 ? many : 1, crc, lg.n);
         drone_vec_close(v);
         free(obs); free(act); free(rew); free(term); free(trunc);
         return 0;
@@ -124,6 +152,18 @@ int main(int argc, char** argv) {
     printf("{\"mode\": \"per-step host buffers (PCIe inclusive)\", \"envs\": %d, \"steps\": %d, \"env_steps_per_s\": %.4g, \"ms_per_step\": %.4f}\n",
            envs, steps, (double)envs * steps / el, el * 1e3 / steps);
 
+    /* (a') K env steps per call with every step's outputs (drone_vec_step_many): one launch and one round of copies per K steps */
+    if (many > 0) {
+        for (int k = 0; k < many; k++) drone_vec_fill_random_actions(v, m_act + (size_t)k * envs * DRONE_ACT_DIM, drone_vec_gstep(v) + (uint32_t)k);
+        drone_vec_step_many(v, many, m_act, m_obs, m_rew, m_term, m_trunc);
+        const int calls = steps / many > 0 ? steps / many : 1;
+        t0 = now_s();
+        for (int c = 0; c < calls; c++) drone_vec_step_many(v, many, m_act, m_obs, m_rew, m_term, m_trunc);
+        el = now_s() - t0;
+        printf("{\"mode\": \"step_many host blocks (PCIe inclusive)\", \"envs\": %d, \"steps_per_call\": %d, \"calls\": %d, \"env_steps_per_s\": %.4g, \"ms_per_env_step\": %.4f}\n",
+               envs, many, calls, (double)envs * many * calls / el, el * 1e3 / ((double)calls * many));
+    }
+
     /* (b) fused rollout: PCIe once per horizon */
     drone_vec_rollout(v, rollout);
     int reps = steps / rollout > 0 ? steps / rollout : 1;
@@ -140,5 +180,6 @@ int main(int argc, char** argv) {
     if (drone_vec_status(v)) { fprintf(stderr, "a call on the handle failed: %s\n", drone_vec_status_message(v)); return 1; }
     drone_vec_close(v);
     free(obs); free(act); free(rew); free(term); free(trunc);
+    free(m_act); free(m_obs); free(m_rew); free(m_term); free(m_trunc);
     return 0;
 }

@@ -81,6 +81,21 @@ def test_c_host_crc_matches_oracle(exe, oracle, task):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("task,many", [(0, 7), (1, 32), (2, 5), (3, 300)])
+def test_c_host_step_many_crc_matches_oracle(exe, oracle, task, many):
+    """The plain-C host stepping through drone_vec_step_many (host blocks, K env steps per call, a ragged last call):
+    the CRC chained over every step's observations / rewards / flags equals the per-step one — and the oracle's."""
+    envs, steps, seed = 4000, 300, 5
+    r = subprocess.run([exe, "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed), "--crc", "1", "--many", str(many)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    want, n = oracle_crc(oracle, task, envs, steps, seed)
+    assert got["steps_per_call"] == many and got["crc32"] == want, f"task {task}: C host crc {got['crc32']:#x} != oracle {want:#x}"
+    assert got["episodes"] == n and n > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("task,rollout", [(0, 0), (1, 0), (3, 0), (0, 32)])
 def test_c_host_mp_gather_matches_oracle(exe, oracle, task, rollout):
     """One rank on the 1-GPU box: fork-before-HIP, RCCL communicator bootstrapped
