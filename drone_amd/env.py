@@ -73,5 +73,32 @@ class Drone:
                 infos.append(log)
         return self.observations, self.rewards, self.terminals, self.truncations, infos
 
+    def step_many(self, actions=None, k_steps=None):
+        """K env steps in ONE launch with every step's outputs (``drone_vec_step_many``): open-loop action segments,
+        action repeat, or — ``actions=None`` with ``k_steps`` — the device-side random policy. ``actions`` is a
+        ``[K][num_envs][4]`` block of the env's buffer kind. Returns K-major ``(observations [K][N][O], rewards,
+        terminals, truncations [K][N], infos)``; the env's per-step buffers are not touched. The blocks are reused
+        from call to call for the same K."""
+        K = int(k_steps if actions is None else actions.shape[0])
+        bufs = getattr(self, "_many", None)
+        if bufs is None or bufs.k_steps != K:
+            bufs = self._many = self.vec.alloc_step_many(K)
+        if actions is not None and actions is not bufs.actions:
+            if self.vec.torch_device is None:
+                bufs.actions[:] = actions
+            else:
+                bufs.actions.copy_(actions, non_blocking=True)
+        if self.vec.torch_device is not None:
+            self.vec.use_torch_stream()
+        self.vec.step_many(bufs, policy=actions is None)
+        before = self.tick
+        self.tick += K
+        infos = []
+        if self.log_interval and before // self.log_interval != self.tick // self.log_interval:
+            log = self.vec.log()
+            if log["n"] > 0:
+                infos.append(log)
+        return bufs.observations, bufs.rewards, bufs.terminals, bufs.truncations, infos
+
     def close(self):
         self.vec.close()

@@ -51,6 +51,39 @@ def test_env_class_matches_oracle_and_reports_logs(oracle, hip, device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("device", [None, "cuda:0"])
+def test_env_class_step_many(oracle, hip, device):
+    """Drone.step_many: K-step action segments (and the device policy) through the PufferLib-shaped class."""
+    from drone_amd.env import Drone
+    from helpers import assert_bits_equal
+
+    n, seed, K = 700, 4, 12
+    env = Drone(num_envs=n, task="hover", device=device, seed=seed, log_interval=16, horizon=30)
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(0, horizon=30))
+    env.reset(seed)
+    o.reset(seed)
+    logs = []
+    for rnd in range(4):
+        acts = np.stack([o.fill_random_actions(gstep=o.gstep + k).copy() for k in range(K)])
+        a_in = acts
+        if device is not None:
+            import torch
+
+            a_in = torch.from_numpy(acts).to(device)
+        want = o.step_many(K, acts)
+        obs, rew, term, trunc, infos = env.step_many(a_in)
+        logs += infos
+        for name, w, g in zip(("obs", "rew", "term", "trunc"), want[:4], (obs, rew, term, trunc)):
+            assert_bits_equal(w, g, f"round {rnd} {name}")
+    want = o.step_many(5, None)
+    obs, rew, term, trunc, infos = env.step_many(k_steps=5)  # the device policy
+    assert_bits_equal(want[0], obs, "policy obs")
+    assert_bits_equal(want[1], rew, "policy rewards")
+    assert len(logs) >= 1 and all(l["n"] > 0 for l in logs)  # the log is read whenever a call crosses a log_interval boundary
+    env.close()
+
+
+@pytest.mark.gpu
 def test_env_class_on_slices_of_a_shared_block(oracle, hip):
     """The PufferLib vec-env contract: the caller allocates ONE block per buffer kind and
     hands every env (worker) a slice of it; two envs here fill one block between them."""
