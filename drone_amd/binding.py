@@ -246,6 +246,18 @@ class DroneVec:
             self._raise_if_failed()
         return bufs
 
+    def step_repeat(self, bufs, actions=None):
+        """Action repeat / frame skip: ``bufs.k_steps`` env steps in one launch under ONE action block ``[N][4]``
+        (default: the handle's bound ``actions``), every step's outputs in ``bufs`` (``drone_vec_step_repeat``)."""
+        actions = self.actions if actions is None else actions
+        if tuple(actions.shape) != (self.num_envs, abi.ACT_DIM) or _is_torch(actions) != (self.torch_device is not None):
+            raise ValueError("step_repeat: actions must be [num_envs][4] of the handle's buffer kind")
+        self._f["drone_vec_step_repeat"](self._h, bufs.k_steps, _ptr(actions), _ptr(bufs.observations), _ptr(bufs.rewards),
+                                         _ptr(bufs.terminals), _ptr(bufs.truncations))
+        if self._status(self._h):
+            self._raise_if_failed()
+        return bufs
+
     def done_list_at(self, k):
         """ids of the envs that finished in step ``k`` of the last ``step_many`` (compact_done=1)."""
         ids = np.zeros(self.num_envs, dtype=np.uint32)

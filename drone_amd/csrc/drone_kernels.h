@@ -46,7 +46,8 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
 hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s);
 // K env steps in one launch with per-step outputs into [K][n]... blocks; act == nullptr: the random policy in-kernel;
 // done_ids [K][n] + done_count [K] (zeroed by the caller on the same stream) or both null
-hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, float* obs, float* rew,
+// act_stride: rows between the action blocks of consecutive steps (n: a [K][n][4] block; 0: one [n][4] block repeated)
+hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, uint32_t act_stride, float* obs, float* rew,
                             unsigned char* term, unsigned char* trunc, uint32_t* done_ids, uint32_t* done_count, hipStream_t s);
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s);
 // partials: [grid][6] doubles; returns grid size via *grid_out. Clears the log planes.

@@ -772,7 +772,8 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
 // keeps the more conservative of the two).
 // =====================================================================
 struct ManyArgs {
-    const float* act;      // [K][n][4], or null: the SPEC.md section 2 random policy, drawn in the kernel
+    const float* act;      // [K][n][4] (act_stride = n), [n][4] applied to all K steps (act_stride = 0: action repeat), or null: the SPEC.md section 2 random policy, drawn in the kernel
+    uint32_t act_stride;   // rows between the action blocks of consecutive steps
     float* obs;            // [K][n][obs_dim]
     float* rew;            // [K][n]
     unsigned char* term;   // [K][n]
@@ -842,13 +843,13 @@ __device__ __forceinline__ void many_loop(const KParams& P, Shared& sh, const St
     float4 a_cur = make_float4(0.f, 0.f, 0.f, 0.f), a_nxt = a_cur;
     if (!POLICY) {
         a_cur = actp[0];
-        a_nxt = actp[(size_t)min(1u, K - 1u) * n];
+        a_nxt = actp[(size_t)min(1u, K - 1u) * m.act_stride];
     }
     // step 0, peeled: the loop below is entered with step 0's stores behind the load of a_nxt, like every later entry
     many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, 0u, gstep0, i, block_base, any_target, any_end);
     for (uint32_t k = 1; k < K; k++) {
         a_cur = a_nxt;
-        if (!POLICY) a_nxt = actp[(size_t)min(k + 1u, K - 1u) * n];  // the NEXT step's row: in flight during this step's arithmetic
+        if (!POLICY) a_nxt = actp[(size_t)min(k + 1u, K - 1u) * m.act_stride];  // the NEXT step's row: in flight during this step's arithmetic
         many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, k, gstep0 + k, i, block_base, any_target, any_end);
     }
 }
@@ -1006,12 +1007,12 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, float* obs, float* rew,
+hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, uint32_t act_stride, float* obs, float* rew,
                             unsigned char* term, unsigned char* trunc, uint32_t* done_ids, uint32_t* done_count, hipStream_t s) {
     drop_stale_error();
     const StepArgs a = make_args(v, gstep0);
     ManyArgs m;
-    m.act = act; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
+    m.act = act; m.act_stride = act_stride; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
     m.done_ids = done_ids; m.done_count = done_count; m.k_steps = k_steps;
     const dim3 g(grid_for(v.n)), b(kBlock);
     const bool compact = done_ids != nullptr, policy = act == nullptr, pk = use_packed(v);

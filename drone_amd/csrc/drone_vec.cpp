@@ -701,8 +701,27 @@ bool many_reserve(DroneVec* v, int k_steps) {
 
 }  // namespace
 
+namespace {
+void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat, float* observations, float* rewards,
+                    unsigned char* terminals, unsigned char* truncations);
+}
+
 void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
                          unsigned char* terminals, unsigned char* truncations) {
+    step_many_impl(v, k_steps, actions, false, observations, rewards, terminals, truncations);
+}
+
+void drone_vec_step_repeat(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
+                           unsigned char* terminals, unsigned char* truncations) {
+    if (!actions) { Entry in(v); if (in) set_err("step_repeat: actions is NULL (the in-kernel policy is drone_vec_step_many with actions = NULL)"); return; }
+    step_many_impl(v, k_steps, actions, true, observations, rewards, terminals, truncations);
+}
+
+namespace {
+
+// `repeat`: `actions` is ONE [N][4] block applied to all k_steps steps (action repeat / frame skip)
+void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat, float* observations, float* rewards,
+                    unsigned char* terminals, unsigned char* truncations) {
     Entry in(v);
     if (!in) return;
     if (k_steps < 1) { set_err("step_many: k_steps must be positive, got %d", k_steps); return; }
@@ -717,13 +736,13 @@ void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* 
     if (v->host_buffers) {
         d_act = actions ? v->s_act : nullptr;
         d_obs = v->s_obs; d_rew = v->s_rew; d_term = v->s_term; d_trunc = v->s_trunc;
-        if (actions) HIP_TRY(hipMemcpyAsync(v->s_act, actions, K * n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return);
+        if (actions) HIP_TRY(hipMemcpyAsync(v->s_act, actions, (repeat ? 1 : K) * n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return);
     } else if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
         set_err("step_many: device blocks must be 16-byte aligned (observations, actions) and 4-byte aligned (rewards)");
         return;
     }
     if (v->cfg.compact_done) HIP_TRY(hipMemsetAsync(v->many_count, 0, sizeof(uint32_t) * K, v->stream), return);
-    HIP_TRY(launch_step_many(v->dv, v->cfg.task, v->gstep, (uint32_t)k_steps, d_act, d_obs, d_rew, d_term, d_trunc,
+    HIP_TRY(launch_step_many(v->dv, v->cfg.task, v->gstep, (uint32_t)k_steps, d_act, repeat ? 0u : (uint32_t)v->n, d_obs, d_rew, d_term, d_trunc,
                              v->cfg.compact_done ? v->many_ids : nullptr, v->cfg.compact_done ? v->many_count : nullptr, v->stream), return);
     v->gstep += (uint32_t)k_steps;
     v->list_valid = false;
@@ -736,6 +755,8 @@ void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* 
         HIP_TRY(hipStreamSynchronize(v->stream), return);
     }
 }
+
+}  // namespace
 
 void drone_vec_log(DroneVec* v, DroneLog* out) {
     if (!out) return;

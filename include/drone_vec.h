@@ -146,6 +146,11 @@ void drone_vec_rollout(DroneVec* v, int horizon);
 void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
                          unsigned char* terminals, unsigned char* truncations);
 
+/* Action repeat (frame skip): the same with ONE actions block [N][4] applied to all k_steps steps — what k_steps calls
+ * of drone_vec_step with an unchanged action buffer would do. Outputs as for drone_vec_step_many: every step's, K-major. */
+void drone_vec_step_repeat(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
+                           unsigned char* terminals, unsigned char* truncations);
+
 void drone_vec_log(DroneVec* v, DroneLog* out);
 void drone_vec_close(DroneVec* v);
 

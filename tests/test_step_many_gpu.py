@@ -169,3 +169,30 @@ def test_step_many_at_config2_size_matches_plain_stepping(hip):
             assert torch.equal(b.terminals, bufs.terminals[k]) and torch.equal(b.truncations, bufs.truncations[k])
     torch.cuda.synchronize()
     assert_state_equal(a.get_state(), b.get_state(), "65536 envs, 128 steps")
+
+
+@pytest.mark.parametrize("task,device", [(0, None), (1, "cuda:0"), (3, "cuda:0")])
+def test_step_repeat_is_k_steps_under_one_action_block(oracle, hip, task, device):
+    """drone_vec_step_repeat (action repeat / frame skip): K env steps in one launch with ONE [N][4] action block —
+    exactly K plain steps with an unchanged action buffer, every step's outputs kept."""
+    n = 2500
+    o, h = pair(oracle, hip, n, 33, task, device=device, horizon=25)
+    bufs = h.alloc_step_many(8)
+    for rep in range(6):
+        acts = o.fill_random_actions(gstep=1000 + rep).copy()
+        if device is None:
+            h.actions[:] = acts
+        else:
+            import torch
+
+            h.actions.copy_(torch.from_numpy(acts))
+        obs, rew, term, trunc, _ = o.step_many(8, np.broadcast_to(acts, (8, n, 4)))
+        h.step_repeat(bufs)
+        if device is not None:
+            torch.cuda.synchronize()
+        assert_bits_equal(obs, to_np(bufs.observations), f"repeat {rep} obs")
+        assert_bits_equal(rew, to_np(bufs.rewards), f"repeat {rep} rewards")
+        assert_bits_equal(term, to_np(bufs.terminals), f"repeat {rep} terminals")
+        assert_bits_equal(trunc, to_np(bufs.truncations), f"repeat {rep} truncations")
+    assert_state_equal(o.get_state(), h.get_state(), "state after repeats")
+    assert h.gstep == o.gstep == 48
