@@ -280,8 +280,7 @@ static PyObject* vec_rollout(PyObject* self, PyObject* args) {
 /* vec_step_many(handle, k_steps, actions | None, observations, rewards, terminals, truncations): K env steps in one
  * launch with every step's outputs, into K-major blocks of the env's buffer kind ([K][N][4] in, [K][N][O] / [K][N] out);
  * actions = None draws the SPEC.md random policy in the kernel. */
-static PyObject* vec_step_many(PyObject* self, PyObject* args) {
-    (void)self;
+static PyObject* step_many_impl(PyObject* args, int repeat) {
     PyObject *cap, *blk[5];
     int k_steps;
     if (!PyArg_ParseTuple(args, "OiOOOOO", &cap, &k_steps, &blk[0], &blk[1], &blk[2], &blk[3], &blk[4])) return NULL;
@@ -289,7 +288,8 @@ static PyObject* vec_step_many(PyObject* self, PyObject* args) {
     if (!h) return NULL;
     if (k_steps < 1) { PyErr_SetString(PyExc_ValueError, "vec_step_many: k_steps must be positive"); return NULL; }
     const size_t K = (size_t)k_steps;
-    const size_t need[5] = {K * h->n * DRONE_ACT_DIM * 4, K * h->n * h->obs_dim * 4, K * h->n * 4, K * h->n, K * h->n};
+    const size_t need[5] = {(repeat ? 1 : K) * h->n * DRONE_ACT_DIM * 4, K * h->n * h->obs_dim * 4, K * h->n * 4, K * h->n, K * h->n};
+    if (repeat && blk[0] == Py_None) { PyErr_SetString(PyExc_ValueError, "vec_step_repeat: actions is None (the in-kernel policy is vec_step_many with actions = None)"); return NULL; }
     static const char* names[5] = {"actions", "observations", "rewards", "terminals", "truncations"};
     void* ptr[5] = {0};
     Py_buffer views[5];
@@ -313,12 +313,24 @@ static PyObject* vec_step_many(PyObject* self, PyObject* args) {
     }
     if (ok) {
         Py_BEGIN_ALLOW_THREADS
-        drone_vec_step_many(h->v, k_steps, (const float*)ptr[0], (float*)ptr[1], (float*)ptr[2], (unsigned char*)ptr[3], (unsigned char*)ptr[4]);
+        if (repeat) drone_vec_step_repeat(h->v, k_steps, (const float*)ptr[0], (float*)ptr[1], (float*)ptr[2], (unsigned char*)ptr[3], (unsigned char*)ptr[4]);
+        else drone_vec_step_many(h->v, k_steps, (const float*)ptr[0], (float*)ptr[1], (float*)ptr[2], (unsigned char*)ptr[3], (unsigned char*)ptr[4]);
         Py_END_ALLOW_THREADS
     }
     for (int i = 0; i < n_views; i++) PyBuffer_Release(&views[i]);
     if (!ok || raise_if_failed(h) < 0) return NULL;
     Py_RETURN_NONE;
+}
+
+static PyObject* vec_step_many(PyObject* self, PyObject* args) {
+    (void)self;
+    return step_many_impl(args, 0);
+}
+
+/* vec_step_repeat(handle, k_steps, actions [N][4], observations, rewards, terminals, truncations): action repeat / frame skip */
+static PyObject* vec_step_repeat(PyObject* self, PyObject* args) {
+    (void)self;
+    return step_many_impl(args, 1);
 }
 
 /* vec_done_list_at(handle, k) -> bytes of uint32 ids (compact_done=1): envs that finished in step k of the last vec_step_many */
@@ -445,6 +457,8 @@ static PyMethodDef methods[] = {
     {"vec_rollout", vec_rollout, METH_VARARGS, "vec_rollout(handle, horizon): fused rollout under the device-side random policy"},
     {"vec_step_many", vec_step_many, METH_VARARGS,
      "vec_step_many(handle, k_steps, actions | None, observations, rewards, terminals, truncations): K env steps in one launch, every step's outputs in K-major blocks"},
+    {"vec_step_repeat", vec_step_repeat, METH_VARARGS,
+     "vec_step_repeat(handle, k_steps, actions [N][4], observations, rewards, terminals, truncations): K env steps under one action block (frame skip), every step's outputs in K-major blocks"},
     {"vec_done_list_at", vec_done_list_at, METH_VARARGS, "vec_done_list_at(handle, k) -> bytes (uint32 ids) of the envs that finished in step k of the last vec_step_many"},
     {"vec_log", vec_log, METH_VARARGS, "vec_log(handle) -> dict(perf, score, episode_return, episode_length, oob, n)"},
     {"vec_close", vec_close, METH_VARARGS, "vec_close(handle)"},

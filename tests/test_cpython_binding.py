@@ -133,7 +133,7 @@ def test_buffer_format_and_size_checks(ext):
         ext.vec_init(b[0], b[1], np.zeros(16, np.int32), b[3], b[4], 16, 0)
     with pytest.raises(TypeError, match="terminals: expected uint8"):
         ext.vec_init(b[0], b[1], b[2], np.zeros(16, np.float32), b[4], 16, 0)
-    assert callable(ext.vec_step_many) and callable(ext.vec_done_list_at)
+    assert callable(ext.vec_step_many) and callable(ext.vec_step_repeat) and callable(ext.vec_done_list_at)
 
 
 @pytest.mark.gpu
@@ -201,4 +201,19 @@ def test_binding_step_many_matches_oracle(ext, oracle, task, device):
     assert_bits_equal(rew, host(blocks[1]), "policy rew")
     with pytest.raises(ValueError, match="observations holds"):
         ext.vec_step_many(h, 6, None, *blocks)
+    # action repeat: ONE [N][4] block for the five steps
+    acts = o.fill_random_actions(gstep=777).copy()
+    one = mk(n, 4)
+    if device:
+        one.copy_(torch.from_numpy(acts))
+    else:
+        one[:] = acts
+    obs, rew, term, trunc, _ = o.step_many(5, np.broadcast_to(acts, (5, n, 4)))
+    ext.vec_step_repeat(h, 5, one, *blocks)
+    if device:
+        torch.cuda.synchronize()
+    assert_bits_equal(obs, host(blocks[0]), "repeat obs")
+    assert_bits_equal(trunc, host(blocks[3]), "repeat truncations")
+    with pytest.raises(ValueError, match="actions is None"):
+        ext.vec_step_repeat(h, 5, None, *blocks)
     ext.vec_close(h)
