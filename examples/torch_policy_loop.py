@@ -5,7 +5,10 @@ copies, one stream. Prints env-steps/s including the policy,
 first launched eagerly (a dozen launches per step: host-bound at small shards),
 then with "policy forward + env step" captured ONCE into a hipGraph
 (torch.cuda.graph) and replayed: graph-safe stepping (drone_vec_enable_graph_capture)
-keeps the step counter in HBM so the replays advance it.
+keeps the step counter in HBM so the replays advance it. Last: the same graph
+with a frame skip of 4 — one policy forward, then four env steps under that
+action in ONE launch (drone_vec_step_repeat), the policy reading the last of the
+four observation blocks.
 
     python examples/torch_policy_loop.py [--envs 65536] [--steps 500] [--task hover]
 """
@@ -27,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--task", default="hover")
     ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--skip", type=int, default=4, help="frame skip of the last loop (env steps per policy step)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     env = Drone(num_envs=a.envs, task=a.task, device=dev, seed=0, log_interval=0)
@@ -79,6 +83,34 @@ def main():
     log = vec.log()
     print(f"captured as one hipGraph per step and replayed: {a.envs * a.steps / el:.3e} env-steps/s ({el * 1e6 / a.steps:.1f} us per step); "
           f"episodes {log['n']:.0f}, mean return {log['episode_return']:.3f}")
+
+    # frame skip: policy forward + K env steps under that action in one launch, captured once
+    K = a.skip
+    bufs = vec.alloc_step_many(K)
+    with torch.no_grad():
+        with torch.cuda.stream(side):
+            vec.use_torch_stream()
+            bufs.observations[K - 1].copy_(vec.observations)
+            for _ in range(3):
+                vec.actions.copy_(policy(bufs.observations[K - 1]))
+                vec.step_repeat(bufs)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            vec.use_torch_stream()
+            vec.actions.copy_(policy(bufs.observations[K - 1]))  # the observation after the previous K steps
+            vec.step_repeat(bufs)
+        g0 = vec.gstep
+        calls = max(1, a.steps // K)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            g.replay()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    assert vec.gstep == g0 + calls * K
+    print(f"frame skip {K} (one policy forward + drone_vec_step_repeat per replay): {a.envs * calls * K / el:.3e} env-steps/s "
+          f"({el * 1e6 / (calls * K):.1f} us per env step, {el * 1e6 / calls:.1f} us per policy step)")
     env.close()
 
 
