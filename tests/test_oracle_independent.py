@@ -224,3 +224,39 @@ def test_unpowered_throw_conserves_total_energy(oracle):
     scale = 0.5 * cfg.mass * (s1["vel"].astype(np.float64) ** 2).sum(1)  # the kinetic term by now dominates
     np.testing.assert_allclose(energy(s1), e0, rtol=0, atol=2e-5 * scale.max())
     v.close()
+
+
+def test_integrator_converges_at_fourth_order(oracle):
+    """A property no transcription error survives: with the step size halved (substeps 1 -> 2 -> 4 at a deliberately
+    coarse dt = 0.04 s) the oracle's distance from a finely resolved float64 solution (the numpy statement at 64
+    substeps) falls by 2^4 per halving — RK4 for the rigid body AND the closed-form rotor lag evaluated at the right
+    stage times (a first-order slip anywhere, e.g. rotor inputs taken at the wrong instant, would show as a ratio of 2).
+    Float32 rounding sets the floor near 1e-5, so the third halving is only required to keep improving."""
+    import drift
+
+    n, seed, dt, steps = 256, 11, 0.04, 10
+
+    def cfg(substeps):
+        return oracle.default_config(0, substeps=substeps, dt=dt, bound=1.0e4, horizon=1 << 30, max_vel=1.0e4, max_omega=1.0e4)
+
+    v0 = oracle.OracleVec(n, seed=seed, cfg=cfg(1), threads=2)
+    v0.reset(seed)
+    acts = [v0.fill_random_actions(gstep=t // 4).copy() * 0.5 for t in range(steps)]  # each action held for four steps
+    rows = v0.get_state()
+    c = sn.derived(cfgdict(cfg(64)))
+    ref = [rows[f].astype(np.float64) for f in drift.FIELDS]
+    for t in range(steps):
+        ref = sn.step(c, ref, acts[t].astype(np.float64), np.zeros((n, 3)))
+    errs = []
+    for s in (1, 2, 4, 8):
+        v = oracle.OracleVec(n, seed=seed, cfg=cfg(s), threads=2)
+        v.reset(seed)
+        for t in range(steps):
+            v.actions[:] = acts[t]
+            v.step()
+            assert not v.terminals.any()
+        got = v.get_state()
+        errs.append(max(float(np.abs(got[f].astype(np.float64) - r).max()) for f, r in zip(drift.FIELDS[:4], ref[:4])))
+    print("error vs substeps 1, 2, 4, 8:", ["%.3e" % e for e in errs])
+    assert 12.0 < errs[0] / errs[1] < 20.0 and 12.0 < errs[1] / errs[2] < 20.0  # 2^4 = 16 per halving
+    assert errs[3] < errs[2] / 4.0                                                # still falling, into the float32 floor
