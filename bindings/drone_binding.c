@@ -17,7 +17,11 @@
  *
  * Buffers: any object exporting a writable C-contiguous buffer (numpy arrays, slices
  * of a shared-memory block) -> DRONE_BUFFERS_HOST; or objects with `data_ptr()` (torch
- * tensors on the GPU) -> DRONE_BUFFERS_DEVICE, zero-copy.
+ * tensors on the GPU) -> DRONE_BUFFERS_DEVICE, zero-copy; or any DLPack producer on a
+ * ROCm device (`__dlpack__`: cupy / jax arrays, torch tensors behind a wrapper) ->
+ * DRONE_BUFFERS_DEVICE as well; or five times None -> the library allocates the buffers
+ * in HBM and vec_dlpack(handle, name) hands them out as DLPack capsules
+ * (torch.from_dlpack / cupy.from_dlpack), SURVEY.md §8 f3.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -28,21 +32,56 @@
 
 #define CAPSULE_NAME "drone_amd.DroneVec"
 
+/* ---- DLPack (the data-interchange ABI of dmlc/dlpack, v0.x unversioned structs): declared here so that the module
+ * needs no header beyond Python.h. Field order and widths are the standard's. ---- */
+enum { kDLCPU = 1, kDLROCM = 10 };
+enum { kDLInt = 0, kDLUInt = 1, kDLFloat = 2, kDLBool = 6 };
+typedef struct DLDevice { int32_t device_type; int32_t device_id; } DLDevice;
+typedef struct DLDataType { uint8_t code; uint8_t bits; uint16_t lanes; } DLDataType;
+typedef struct DLTensor {
+    void* data;
+    DLDevice device;
+    int32_t ndim;
+    DLDataType dtype;
+    int64_t* shape;
+    int64_t* strides; /* in elements; NULL = compact row-major */
+    uint64_t byte_offset;
+} DLTensor;
+typedef struct DLManagedTensor {
+    DLTensor dl_tensor;
+    void* manager_ctx;
+    void (*deleter)(struct DLManagedTensor* self);
+} DLManagedTensor;
+#define DLPACK_CAPSULE "dltensor"
+#define DLPACK_CAPSULE_USED "used_dltensor"
+
 typedef struct Handle {
     DroneVec* v;
     Py_buffer views[5]; /* host mode: keeps the exporters' memory pinned while the env uses it */
     int n_views;
     PyObject* keep[5];  /* device mode: strong references to the tensors */
     int n_keep;
+    DLManagedTensor* imported[5]; /* device mode, DLPack producers: the managed tensors this env consumed (released at close) */
+    int n_imported;
     size_t n, obs_dim;  /* envs, floats per observation row */
     int device_kind;    /* 1: buffers are device tensors */
+    int exports;        /* DLPack views of the env's buffers handed out by vec_dlpack and not yet deleted */
 } Handle;
+
+static void release_buffers(Handle* h) {
+    for (int i = 0; i < h->n_views; i++) PyBuffer_Release(&h->views[i]);
+    h->n_views = 0;
+    for (int i = 0; i < h->n_keep; i++) Py_XDECREF(h->keep[i]);
+    h->n_keep = 0;
+    for (int i = 0; i < h->n_imported; i++)
+        if (h->imported[i] && h->imported[i]->deleter) h->imported[i]->deleter(h->imported[i]);
+    h->n_imported = 0;
+}
 
 static void handle_free(Handle* h) {
     if (!h) return;
     if (h->v) drone_vec_close(h->v);
-    for (int i = 0; i < h->n_views; i++) PyBuffer_Release(&h->views[i]);
-    for (int i = 0; i < h->n_keep; i++) Py_XDECREF(h->keep[i]);
+    release_buffers(h);
     PyMem_Free(h);
 }
 
@@ -109,15 +148,54 @@ static int apply_kwargs(DroneConfig* cfg, PyObject* kwargs) {
     return 0;
 }
 
-/* a device tensor: has data_ptr(); returns 1 and the address, 0 if not that kind, -1 on error */
+/* a device tensor: has data_ptr(); returns 1 and the address, 0 if not that kind, -1 on error.
+ * 2 (no address yet): no data_ptr() but a DLPack producer — see dl_import. */
 static int device_pointer(PyObject* o, void** out) {
-    if (!PyObject_HasAttrString(o, "data_ptr")) return 0;
+    if (!PyObject_HasAttrString(o, "data_ptr")) return PyObject_HasAttrString(o, "__dlpack__") && !PyObject_CheckBuffer(o) ? 2 : 0;
     PyObject* r = PyObject_CallMethod(o, "data_ptr", NULL);
     if (!r) return -1;
     *out = PyLong_AsVoidPtr(r);
     Py_DECREF(r);
     if (PyErr_Occurred()) return -1;
     return 1;
+}
+
+/* Consume `o.__dlpack__()`: a compact row-major ROCm tensor of f32 (want_float) or one-byte items holding at least
+ * need_bytes. On success the managed tensor is OURS (*out; release with its deleter), *ptr its first element and
+ * *device its HIP ordinal. */
+static int dl_import(PyObject* o, int want_float, size_t need_bytes, const char* name, DLManagedTensor** out, void** ptr, int* device) {
+    PyObject* cap = PyObject_CallMethod(o, "__dlpack__", NULL);
+    if (!cap) return -1;
+    DLManagedTensor* m = (DLManagedTensor*)PyCapsule_GetPointer(cap, DLPACK_CAPSULE);
+    if (!m) { Py_DECREF(cap); return -1; }
+    const DLTensor* t = &m->dl_tensor;
+    const char* why = NULL;
+    int type_error = 0;
+    size_t items = 1;
+    for (int d = 0; d < t->ndim; d++) items *= (size_t)t->shape[d];
+    if (t->device.device_type != kDLROCM) why = "is not on a ROCm device";
+    else if (t->dtype.lanes != 1 || (want_float ? !(t->dtype.code == kDLFloat && t->dtype.bits == 32)
+                                               : !((t->dtype.code == kDLUInt || t->dtype.code == kDLInt || t->dtype.code == kDLBool) && t->dtype.bits == 8)))
+        why = want_float ? "must hold float32 items" : "must hold uint8 / bool items", type_error = 1;
+    else if (items * (want_float ? 4u : 1u) < need_bytes) why = "is too small";
+    if (!why && t->strides) { /* compact row-major, ignoring extent-1 dimensions */
+        int64_t expect = 1;
+        for (int d = t->ndim - 1; d >= 0; d--) {
+            if (t->shape[d] != 1 && t->strides[d] != expect) { why = "must be contiguous"; break; }
+            expect *= t->shape[d];
+        }
+    }
+    if (why) {
+        PyErr_Format(type_error ? PyExc_TypeError : PyExc_ValueError, "%s (DLPack): %s", name, why);
+        Py_DECREF(cap); /* still named "dltensor": the producer's capsule destructor releases it */
+        return -1;
+    }
+    if (PyCapsule_SetName(cap, DLPACK_CAPSULE_USED) != 0) { Py_DECREF(cap); return -1; }
+    Py_DECREF(cap);
+    *out = m;
+    *ptr = (char*)t->data + t->byte_offset;
+    *device = t->device.device_id;
+    return 0;
 }
 
 /* Host buffers must hold what the env writes through them: f32 items for observations / actions / rewards, one-byte
@@ -191,10 +269,33 @@ static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
     const size_t need[5] = {(size_t)num_envs * od * 4, (size_t)num_envs * DRONE_ACT_DIM * 4, (size_t)num_envs * 4, (size_t)num_envs, (size_t)num_envs};
     static const char* names[5] = {"observations", "actions", "rewards", "terminals", "truncations"};
     int kind = -1; /* 0 host, 1 device */
-    for (int i = 0; i < 5; i++) {
+    int n_none = 0;
+    for (int i = 0; i < 5; i++) n_none += bufs[i] == Py_None;
+    if (n_none && n_none != 5) {
+        PyErr_SetString(PyExc_TypeError, "vec_init: pass all five buffers, or None five times for library-owned device buffers");
+        handle_free(h);
+        return NULL;
+    }
+    const int have_device_kwarg = kwargs && PyDict_GetItemString(kwargs, "device") != NULL;
+    for (int i = 0; i < 5 && !n_none; i++) {
         void* d = NULL;
-        const int isdev = device_pointer(bufs[i], &d);
+        int isdev = device_pointer(bufs[i], &d);
         if (isdev < 0) { handle_free(h); return NULL; }
+        if (isdev == 2) { /* a DLPack producer: the env consumes its managed tensor and keeps it until close */
+            int dl_dev = 0;
+            if (dl_import(bufs[i], i < 3, need[i], names[i], &h->imported[h->n_imported], &d, &dl_dev) < 0) { handle_free(h); return NULL; }
+            h->n_imported++;
+            if (!have_device_kwarg && h->n_imported == 1) cfg.device = dl_dev;
+            if (dl_dev != cfg.device) {
+                PyErr_Format(PyExc_ValueError, "vec_init: %s lives on ROCm device %d, the env on device %d", names[i], dl_dev, cfg.device);
+                handle_free(h);
+                return NULL;
+            }
+            if (kind == 0) { PyErr_SetString(PyExc_TypeError, "vec_init: buffers must be all host buffers or all device tensors"); handle_free(h); return NULL; }
+            kind = 1;
+            ptr[i] = d;
+            continue;
+        }
         if (kind >= 0 && kind != isdev) {
             PyErr_SetString(PyExc_TypeError, "vec_init: buffers must be all host buffers or all device tensors");
             handle_free(h);
@@ -218,6 +319,7 @@ static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
             ptr[i] = h->views[i].buf;
         }
     }
+    if (n_none) kind = 1; /* ptr[] stays NULL: drone_vec_init allocates */
     cfg.buffer_kind = kind ? DRONE_BUFFERS_DEVICE : DRONE_BUFFERS_HOST;
     h->n = (size_t)num_envs;
     h->obs_dim = od;
@@ -293,12 +395,21 @@ static PyObject* step_many_impl(PyObject* args, int repeat) {
     static const char* names[5] = {"actions", "observations", "rewards", "terminals", "truncations"};
     void* ptr[5] = {0};
     Py_buffer views[5];
-    int n_views = 0, ok = 1;
+    DLManagedTensor* lent[5]; /* DLPack producers: held for the duration of the call */
+    int n_views = 0, n_lent = 0, ok = 1;
     for (int i = 0; i < 5 && ok; i++) {
         if (i == 0 && blk[0] == Py_None) continue; /* device policy */
         void* d = NULL;
-        const int isdev = device_pointer(blk[i], &d);
+        int isdev = device_pointer(blk[i], &d);
         if (isdev < 0) { ok = 0; break; }
+        if (isdev == 2 && h->device_kind) {
+            int dl_dev = 0;
+            if (dl_import(blk[i], i < 3, need[i], names[i], &lent[n_lent], &d, &dl_dev) < 0) { ok = 0; break; }
+            n_lent++;
+            if (dl_dev != drone_vec_device(h->v)) { PyErr_Format(PyExc_ValueError, "vec_step_many: %s lives on ROCm device %d, the env on device %d", names[i], dl_dev, drone_vec_device(h->v)); ok = 0; break; }
+            ptr[i] = d;
+            continue;
+        }
         if (isdev != h->device_kind) { PyErr_Format(PyExc_TypeError, "vec_step_many: %s must be of the env's buffer kind (host buffer / device tensor)", names[i]); ok = 0; break; }
         if (isdev) {
             if (check_device_tensor(blk[i], i < 3, need[i], names[i]) < 0) { ok = 0; break; }
@@ -318,6 +429,8 @@ static PyObject* step_many_impl(PyObject* args, int repeat) {
         Py_END_ALLOW_THREADS
     }
     for (int i = 0; i < n_views; i++) PyBuffer_Release(&views[i]);
+    for (int i = 0; i < n_lent; i++)
+        if (lent[i]->deleter) lent[i]->deleter(lent[i]); /* the caller's object keeps the memory, as with data_ptr() tensors */
     if (!ok || raise_if_failed(h) < 0) return NULL;
     Py_RETURN_NONE;
 }
@@ -371,15 +484,83 @@ static PyObject* vec_close(PyObject* self, PyObject* args) {
     if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
     Handle* h = (Handle*)PyCapsule_GetPointer(cap, CAPSULE_NAME);
     if (!h) return NULL;
+    if (h->exports > 0) { /* tensors made from vec_dlpack capsules still point into the env's buffers */
+        PyErr_Format(PyExc_RuntimeError, "vec_close: %d DLPack view(s) of this env's buffers are still alive; delete them first", h->exports);
+        return NULL;
+    }
     if (h->v) {
         drone_vec_close(h->v);
         h->v = NULL;
     }
-    for (int i = 0; i < h->n_views; i++) PyBuffer_Release(&h->views[i]);
-    h->n_views = 0;
-    for (int i = 0; i < h->n_keep; i++) Py_XDECREF(h->keep[i]);
-    h->n_keep = 0;
+    release_buffers(h);
     Py_RETURN_NONE;
+}
+
+/* ---- DLPack export ---- */
+typedef struct Export {
+    DLManagedTensor m; /* first: the deleter gets &m */
+    int64_t shape[2];
+    PyObject* owner;   /* the env handle capsule: the buffers live as long as it does */
+    Handle* h;
+} Export;
+
+static void export_deleter(DLManagedTensor* m) {
+    Export* e = (Export*)m;
+    if (Py_IsInitialized()) { /* consumers may drop the tensor from any thread, without the GIL */
+        PyGILState_STATE g = PyGILState_Ensure();
+        e->h->exports--;
+        Py_DECREF(e->owner);
+        PyGILState_Release(g);
+    }
+    free(e);
+}
+
+static void export_capsule_destructor(PyObject* cap) { /* never consumed: the capsule still owns the managed tensor */
+    if (!PyCapsule_IsValid(cap, DLPACK_CAPSULE)) return; /* renamed "used_dltensor": the consumer owns it */
+    DLManagedTensor* m = (DLManagedTensor*)PyCapsule_GetPointer(cap, DLPACK_CAPSULE);
+    if (m && m->deleter) m->deleter(m);
+}
+
+/* vec_dlpack(handle, name) -> DLPack capsule of one of the env's DEVICE buffers as bound now: "observations" [N][O] f32,
+ * "actions" [N][4] f32, "rewards" [N] f32, "terminals" / "truncations" [N] u8 — zero-copy, on ROCm device
+ * drone_vec_device(). torch.from_dlpack(capsule) / cupy.from_dlpack wrap it; the env (and with it the memory) stays
+ * alive until every such tensor is gone, and vec_close refuses to run before that. */
+static PyObject* vec_dlpack(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    const char* name;
+    if (!PyArg_ParseTuple(args, "Os", &cap, &name)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    if (!h->device_kind) { PyErr_SetString(PyExc_TypeError, "vec_dlpack: this env uses host buffers (the caller's own arrays)"); return NULL; }
+    float *obs, *act, *rew;
+    unsigned char *term, *trunc;
+    if (drone_vec_buffers(h->v, &obs, &act, &rew, &term, &trunc) != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
+    Export* e = (Export*)calloc(1, sizeof(Export));
+    if (!e) return PyErr_NoMemory();
+    DLTensor* t = &e->m.dl_tensor;
+    t->shape = e->shape;
+    t->shape[0] = (int64_t)h->n;
+    t->ndim = 1;
+    t->dtype.lanes = 1;
+    t->dtype.code = kDLFloat;
+    t->dtype.bits = 32;
+    if (!strcmp(name, "observations")) { t->data = obs; t->ndim = 2; t->shape[1] = (int64_t)h->obs_dim; }
+    else if (!strcmp(name, "actions")) { t->data = act; t->ndim = 2; t->shape[1] = DRONE_ACT_DIM; }
+    else if (!strcmp(name, "rewards")) t->data = rew;
+    else if (!strcmp(name, "terminals") || !strcmp(name, "truncations")) { t->data = name[1] == 'e' ? term : trunc; t->dtype.code = kDLUInt; t->dtype.bits = 8; }
+    else { free(e); PyErr_Format(PyExc_ValueError, "vec_dlpack: unknown buffer '%s'", name); return NULL; }
+    t->device.device_type = kDLROCM;
+    t->device.device_id = drone_vec_device(h->v);
+    e->m.deleter = export_deleter;
+    e->m.manager_ctx = e;
+    e->h = h;
+    PyObject* out = PyCapsule_New(&e->m, DLPACK_CAPSULE, export_capsule_destructor);
+    if (!out) { free(e); return NULL; }
+    Py_INCREF(cap);
+    e->owner = cap;
+    h->exports++;
+    return out;
 }
 
 /* vec_set_stream(handle, hip_stream_address): device-buffer mode launches on this stream from now on */
@@ -409,15 +590,21 @@ static PyObject* vec_fill_random_actions(PyObject* self, PyObject* args) {
     void* p = NULL;
     Py_buffer view;
     int have_view = 0;
-    if (buf == Py_None) {
-        p = h->n_views ? h->views[1].buf : NULL;
-        if (!p && h->n_keep && device_pointer(h->keep[1], &p) < 0) return NULL;
+    DLManagedTensor* lent = NULL;
+    if (buf == Py_None) { /* the env's bound action buffer, whoever owns it */
+        float* a = NULL;
+        if (drone_vec_buffers(h->v, NULL, &a, NULL, NULL, NULL) != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
+        p = a;
     } else {
-        const int isdev = device_pointer(buf, &p);
+        int isdev = device_pointer(buf, &p);
         if (isdev < 0) return NULL;
-        if (isdev != h->device_kind) { PyErr_SetString(PyExc_TypeError, "vec_fill_random_actions: the buffer must be of the env's buffer kind (host buffer / device tensor)"); return NULL; }
         const size_t need = h->n * DRONE_ACT_DIM * 4;  /* the library writes this many bytes through the pointer */
-        if (isdev) {
+        if (isdev == 2 && h->device_kind) {
+            int dl_dev = 0;
+            if (dl_import(buf, 1, need, "actions", &lent, &p, &dl_dev) < 0) return NULL;
+            if (dl_dev != drone_vec_device(h->v)) { lent->deleter(lent); PyErr_SetString(PyExc_ValueError, "vec_fill_random_actions: actions lives on another device"); return NULL; }
+        } else if (isdev != h->device_kind) { PyErr_SetString(PyExc_TypeError, "vec_fill_random_actions: the buffer must be of the env's buffer kind (host buffer / device tensor)"); return NULL; }
+        else if (isdev) {
             if (check_device_tensor(buf, 1, need, "actions") < 0) return NULL;
         } else {
             if (PyObject_GetBuffer(buf, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) return NULL;
@@ -429,6 +616,7 @@ static PyObject* vec_fill_random_actions(PyObject* self, PyObject* args) {
     }
     const int rc = drone_vec_fill_random_actions(h->v, (float*)p, g);
     if (have_view) PyBuffer_Release(&view);
+    if (lent && lent->deleter) lent->deleter(lent);
     if (rc != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
     Py_RETURN_NONE;
 }
@@ -462,6 +650,7 @@ static PyMethodDef methods[] = {
     {"vec_done_list_at", vec_done_list_at, METH_VARARGS, "vec_done_list_at(handle, k) -> bytes (uint32 ids) of the envs that finished in step k of the last vec_step_many"},
     {"vec_log", vec_log, METH_VARARGS, "vec_log(handle) -> dict(perf, score, episode_return, episode_length, oob, n)"},
     {"vec_close", vec_close, METH_VARARGS, "vec_close(handle)"},
+    {"vec_dlpack", vec_dlpack, METH_VARARGS, "vec_dlpack(handle, name) -> DLPack capsule (ROCm device) of the env's observations / actions / rewards / terminals / truncations"},
     {"vec_set_stream", vec_set_stream, METH_VARARGS, "vec_set_stream(handle, hip_stream_address)"},
     {"vec_fill_random_actions", vec_fill_random_actions, METH_VARARGS, "vec_fill_random_actions(handle, actions=None, gstep=None)"},
     {"vec_gstep", vec_gstep, METH_VARARGS, "vec_gstep(handle) -> int"},

@@ -107,6 +107,8 @@ SYMBOLS = {
     "drone_vec_fill_random_actions": (C.c_int, [_P, _P, C.c_uint32]),
     "drone_vec_gstep": (C.c_uint32, [_P]),
     "drone_vec_num_envs": (C.c_int, [_P]),
+    "drone_vec_buffers": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "drone_vec_device": (C.c_int, [_P]),
     "drone_vec_set_gstep": (C.c_int, [_P, C.c_uint32]),
     "drone_vec_enable_graph_capture": (C.c_int, [_P, C.c_int]),
     "drone_vec_status": (C.c_int, [_P]),

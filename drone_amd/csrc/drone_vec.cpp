@@ -92,7 +92,7 @@ struct DroneVec {
     uint32_t* d_kp;
     double* d_partials;
     double* h_partials;  // pinned
-    float* d_obs;        // device mirrors (host-buffer mode only)
+    float* d_obs;        // host-buffer handles: device mirrors; device handles: the library-owned buffers, if any
     float* d_act;
     float* d_rew;
     unsigned char* d_term;
@@ -504,13 +504,30 @@ int drone_vec_bytes_per_env_step(const DroneVec* v) {
 
 int drone_vec_host_transport(const DroneVec* v) { return !v ? -1 : !v->host_buffers ? -1 : v->zero_copy ? 1 : 0; }
 
+int drone_vec_buffers(const DroneVec* v, float** observations, float** actions, float** rewards, unsigned char** terminals, unsigned char** truncations) {
+    if (!v) { set_err("NULL handle"); return -1; }
+    if (observations) *observations = v->u_obs;
+    if (actions) *actions = v->u_act;
+    if (rewards) *rewards = v->u_rew;
+    if (terminals) *terminals = v->u_term;
+    if (truncations) *truncations = v->u_trunc;
+    return 0;
+}
+
+int drone_vec_device(const DroneVec* v) { return v ? v->device : -1; }
+
 int drone_obs_dim(int task) { return (task == DRONE_TASK_SWARM || task == DRONE_TASK_RACE) ? DRONE_OBS_DIM_MAX : DRONE_OBS_DIM; }
 
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, unsigned char* terminals,
                          unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {
     g_err[0] = 0;
     if (!validate(cfg, num_envs)) return nullptr;
-    if (!observations || !actions || !rewards || !terminals || !truncations) { set_err("buffer pointer is NULL"); return nullptr; }
+    // all five NULL on a device-buffer handle: the library allocates them in HBM (drone_vec_buffers hands them out)
+    const bool lib_buffers = cfg->buffer_kind == DRONE_BUFFERS_DEVICE && !observations && !actions && !rewards && !terminals && !truncations;
+    if (!lib_buffers && (!observations || !actions || !rewards || !terminals || !truncations)) {
+        set_err("buffer pointer is NULL (only a DRONE_BUFFERS_DEVICE handle may pass all five as NULL: library-owned buffers)");
+        return nullptr;
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev), return nullptr);
     if (ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) { set_err("HIP device %d not available (%d devices): this library has no CPU path", cfg->device, ndev); return nullptr; }
@@ -595,6 +612,21 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
             }
         }
     } else {
+        if (lib_buffers) {  // freed at close like the host handles' mirrors, which these fields otherwise hold
+            const size_t ob = n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float);
+            INIT_TRY(hipMalloc((void**)&v->d_obs, ob));
+            INIT_TRY(hipMalloc((void**)&v->d_act, n * DRONE_ACT_DIM * sizeof(float)));
+            INIT_TRY(hipMalloc((void**)&v->d_rew, n * sizeof(float)));
+            INIT_TRY(hipMalloc((void**)&v->d_term, n));
+            INIT_TRY(hipMalloc((void**)&v->d_trunc, n));
+            INIT_TRY(hipMemsetAsync(v->d_obs, 0, ob, v->stream));
+            INIT_TRY(hipMemsetAsync(v->d_act, 0, n * DRONE_ACT_DIM * sizeof(float), v->stream));
+            INIT_TRY(hipMemsetAsync(v->d_rew, 0, n * sizeof(float), v->stream));
+            INIT_TRY(hipMemsetAsync(v->d_term, 0, n, v->stream));
+            INIT_TRY(hipMemsetAsync(v->d_trunc, 0, n, v->stream));
+            observations = v->d_obs; actions = v->d_act; rewards = v->d_rew; terminals = v->d_term; truncations = v->d_trunc;
+            v->u_obs = observations; v->u_act = actions; v->u_rew = rewards; v->u_term = terminals; v->u_trunc = truncations;
+        }
         if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
             set_err("device buffers must be 16-byte aligned (observations, actions) and 4-byte aligned (rewards)");
             drone_vec_close(v);

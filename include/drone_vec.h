@@ -113,7 +113,10 @@ int drone_obs_dim(int task);
 
 /* observations [N][drone_obs_dim(task)] f32, actions [N][4] f32, rewards [N] f32,
  * terminals [N] u8, truncations [N] u8 — owned by the caller, never freed
- * here. Returns NULL on failure (see drone_last_error). Does not reset. */
+ * here. Returns NULL on failure (see drone_last_error). Does not reset.
+ * A DRONE_BUFFERS_DEVICE handle may pass all five as NULL: the library then allocates them (zeroed) in HBM on
+ * cfg.device, frees them at close, and drone_vec_buffers hands out the addresses — for consumers that wrap device
+ * memory they did not allocate (DLPack: bindings/drone_binding.c vec_dlpack). */
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards,
                          unsigned char* terminals, unsigned char* truncations,
                          int num_envs, uint64_t seed, const DroneConfig* cfg);
@@ -177,6 +180,12 @@ int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep);
 
 uint32_t drone_vec_gstep(const DroneVec* v);
 int drone_vec_num_envs(const DroneVec* v);
+
+/* The five buffers the handle is bound to now (the caller's, the last rebind's, or the library-owned ones), any of
+ * the out-pointers may be NULL; and the HIP device ordinal the handle lives on (-1 for a NULL handle). */
+int drone_vec_buffers(const DroneVec* v, float** observations, float** actions, float** rewards,
+                      unsigned char** terminals, unsigned char** truncations);
+int drone_vec_device(const DroneVec* v);
 
 /* Restore the vec-level step counter (checkpoints): wind gusts and the random
  * policy are keyed on it (SPEC.md §2), so a run restored with set_state +
