@@ -3,7 +3,7 @@
 
 Each case draws a task, a shard size (ragged sizes included), buffer kind, horizon, substeps, time step, scaled physics
 constants, env offset, the per-handle kernel variants (derived-target layout, packed RK4, graph-safe counters) and then a
-random SEQUENCE of path calls — step (random-policy, hostile or repeated actions), step_many (caller actions or the
+random SEQUENCE of path calls — step (random-policy, hostile or repeated actions, or the product's own fill_random_actions), rebinds of the action / output buffers, step_many (caller actions or the
 in-kernel policy), step_repeat, fused rollout, log, state read-back, a checkpoint round trip through get_state /
 set_state / set_gstep — mirrored call for call on the oracle. Every output of every call, every done-id list and the
 final state must match bit for bit.
@@ -48,9 +48,11 @@ def draw_case(rng):
         for name in rng.choice(SCALED, size=int(rng.integers(1, 6)), replace=False):
             over[str(name)] = ("scale", float(rng.uniform(0.5, 2.0)))
     env = {"DRONE_DERIVED_TARGET": rng.choice(["", "0", "1"]), "DRONE_PACKED_RK4": rng.choice(["", "0", "1"]),
-           "DRONE_LINE_COMPLETE": rng.choice(["", "0", "1"]), "DRONE_SWEEP_ORDER": rng.choice(["", "0", "1", "6"])}
+           "DRONE_LINE_COMPLETE": rng.choice(["", "0", "1"]), "DRONE_SWEEP_ORDER": rng.choice(["", "0", "1", "6"]),
+           "DRONE_HOST_ZEROCOPY": rng.choice(["", "0", "1"])}
     return {"task": task, "n": n, "seed": int(rng.integers(0, 1 << 62)), "device": bool(rng.integers(0, 2)), "over": over, "env": env,
-            "graph_safe": bool(rng.random() < 0.25), "ops": int(rng.integers(4, 14))}
+            "graph_safe": bool(rng.random() < 0.25), "ops": int(rng.integers(4, 14)),
+            "heap_buffers": bool(rng.random() < 0.3)}  # host handles: plain numpy arrays (pages shared with the heap: never pinned) instead of page-owning ones
 
 
 def make_cfg(mod, task, over):
@@ -82,9 +84,24 @@ def put(dst, src):
         dst[...] = src
 
 
+def to_np_(x):
+    return x.cpu().numpy() if type(x).__module__.startswith("torch") else np.asarray(x)
+
+
 def sync(v):
     if v.torch_device is not None:
         v.sync()
+
+
+def fresh_buffers(case):
+    """A set of caller-owned buffers of the case's kind, NOT page-owning for host handles: (obs, act, rew, term, trunc)."""
+    n, od = case["n"], abi.obs_dim(case["task"])
+    if case["device"]:
+        import torch
+
+        return (torch.zeros(n, od, device="cuda:0"), torch.zeros(n, 4, device="cuda:0"), torch.zeros(n, device="cuda:0"),
+                torch.zeros(n, dtype=torch.uint8, device="cuda:0"), torch.zeros(n, dtype=torch.uint8, device="cuda:0"))
+    return (np.zeros((n, od), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
 
 
 def make_vec(binding, case):
@@ -96,7 +113,8 @@ def make_vec(binding, case):
         else:
             os.environ.pop(k, None)
     try:
-        v = binding.DroneVec(case["n"], seed=case["seed"], cfg=make_cfg(binding, case["task"], case["over"]), device="cuda:0" if case["device"] else None)
+        v = binding.DroneVec(case["n"], seed=case["seed"], cfg=make_cfg(binding, case["task"], case["over"]), device="cuda:0" if case["device"] else None,
+                             buffers=fresh_buffers(case) if (case.get("heap_buffers") and not case["device"]) else None)
     finally:
         for k, val in saved.items():
             if val is None:
@@ -122,7 +140,7 @@ def run_case(binding, oracle, case, rng, threads=8):
     compact = bool(case["over"]["compact_done"])
     history = []
     for i in range(case["ops"]):
-        op = str(rng.choice(["step", "step", "hostile", "repeat_last", "many", "many_policy", "step_repeat", "rollout", "log", "state", "checkpoint"]))
+        op = str(rng.choice(["step", "step", "hostile", "repeat_last", "many", "many_policy", "step_repeat", "rollout", "log", "state", "checkpoint", "rebind", "fill"]))
         history.append(op)
         what = f"{tag} after {history[:-1]} op {i} {op}"
         if op in ("step", "hostile", "repeat_last"):
@@ -179,6 +197,28 @@ def run_case(binding, oracle, case, rng, threads=8):
             first = int(rng.integers(0, n))
             count = int(rng.integers(1, n - first + 1))
             assert_state_equal(o.get_state(first, count), v.get_state(first, count), what + f" rows [{first}, {first + count})")
+        elif op == "rebind":
+            # the caller moves to other buffers (a second output set for overlap, a pre-filled action buffer) and lets the old ones go
+            sync(v)
+            obs, act, rew, term, trunc = fresh_buffers(case)
+            which = int(rng.integers(0, 3))
+            if which != 1:
+                v.bind_outputs(obs, rew, term, trunc)
+            if which != 0:
+                put(act, to_np_(v.actions))
+                v.bind_actions(act)
+        elif op == "fill":
+            # the product's own random policy into ITS action buffer, then a step from it
+            g = o.gstep
+            o.fill_random_actions(g)
+            v.fill_random_actions(g)
+            sync(v)
+            assert_bits_equal(o.actions, v.actions, what + " actions")
+            o.step()
+            v.step()
+            sync(v)
+            assert_outputs_equal(o, v, what)
+            env_steps += n
         elif op == "checkpoint":
             # restore the oracle's rows into a FRESH product handle and continue from there
             rows, g = o.get_state(), o.gstep
