@@ -28,14 +28,15 @@ from drone_amd import abi  # noqa: E402
 from helpers import assert_bits_equal, assert_outputs_equal, assert_state_equal  # noqa: E402
 
 SIZES = [1, 2, 63, 64, 65, 127, 255, 256, 257, 1000, 1024, 4097, 8192, 16384 + 17, 32768]
+BIG_SIZES = [65536 + 1, 131072, 262144 + 65, 524288 - 63, 1048576, 1048576 + 3]  # --big: many workgroups per XCD, the size-dependent layout choices taken for real
 SCALED = ["mass", "arm", "ixx", "iyy", "izz", "k_thrust", "k_torque", "k_drag", "k_ang_damp", "motor_tau", "max_vel", "max_omega",
           "bound", "spawn_extent", "target_extent", "tilt_init", "hover_radius", "waypoint_radius", "wind_theta", "wind_sigma", "wind_max",
           "c_omega", "c_action", "crash_penalty", "progress_scale", "waypoint_bonus", "collision_radius", "proximity_radius", "c_proximity", "gate_radius"]
 
 
-def draw_case(rng):
+def draw_case(rng, big=False):
     task = int(rng.integers(0, 4))
-    n = int(rng.choice(SIZES))
+    n = int(rng.choice(BIG_SIZES if big else SIZES))
     over = {"horizon": int(rng.choice([1, 2, 7, 33, 100, 300, 1000])), "substeps": int(rng.integers(1, 4)),
             "dt": float(rng.choice([0.005, 0.01, 0.02, 0.03])), "compact_done": int(rng.integers(0, 2))}
     agents = 1
@@ -51,7 +52,7 @@ def draw_case(rng):
            "DRONE_LINE_COMPLETE": rng.choice(["", "0", "1"]), "DRONE_SWEEP_ORDER": rng.choice(["", "0", "1", "6"]),
            "DRONE_HOST_ZEROCOPY": rng.choice(["", "0", "1"])}
     return {"task": task, "n": n, "seed": int(rng.integers(0, 1 << 62)), "device": bool(rng.integers(0, 2)), "over": over, "env": env,
-            "graph_safe": bool(rng.random() < 0.25), "ops": int(rng.integers(4, 14)),
+            "graph_safe": bool(rng.random() < 0.25), "ops": int(rng.integers(3, 7) if big else rng.integers(4, 14)), "max_k": 3 if big else 9,
             "heap_buffers": bool(rng.random() < 0.3)}  # host handles: plain numpy arrays (pages shared with the heap: never pinned) instead of page-owning ones
 
 
@@ -159,7 +160,7 @@ def run_case(binding, oracle, case, rng, threads=8):
                     assert_bits_equal(want, np.sort(v.done_list()), what + " done list")
                 env_steps += n
         elif op in ("many", "many_policy", "step_repeat"):
-            K = int(rng.integers(1, 10))
+            K = int(rng.integers(1, case.get("max_k", 9) + 1))
             bufs = v.alloc_step_many(K)
             if op == "many":
                 acts = np.stack([hostile_actions(rng, n) if rng.random() < 0.3 else rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(K)])
@@ -182,7 +183,7 @@ def run_case(binding, oracle, case, rng, threads=8):
                     assert_bits_equal(oo[4][k], np.sort(v.done_list_at(k)), f"{what} done list of step {k}")
             env_steps += n * K
         elif op == "rollout":
-            h = int(rng.integers(1, 48))
+            h = int(rng.integers(1, 12 if n > 65536 else 48))
             o.rollout(h)
             v.rollout(h)
             sync(v)
@@ -237,17 +238,17 @@ def run_case(binding, oracle, case, rng, threads=8):
     return env_steps
 
 
-def soak(binding, oracle, seed, cases=None, minutes=None, log=None, threads=8):
+def soak(binding, oracle, seed, cases=None, minutes=None, log=None, threads=8, big=False):
     rng = np.random.default_rng(seed)
     t0 = time.time()
     done = env_steps = 0
     per_task = [0, 0, 0, 0]
     while (cases is None or done < cases) and (minutes is None or time.time() - t0 < minutes * 60):
-        case = draw_case(rng)
+        case = draw_case(rng, big)
         env_steps += run_case(binding, oracle, case, rng, threads)
         per_task[case["task"]] += 1
         done += 1
-        if log and done % 50 == 0:
+        if log and done % (5 if big else 50) == 0:
             print(f"[soak] {done} cases, {env_steps:.3e} env-steps compared, {time.time() - t0:.0f} s", file=log, flush=True)
     return {"cases": done, "env_steps_compared": env_steps, "cases_per_task": per_task, "seconds": time.time() - t0, "seed": seed}
 
@@ -259,6 +260,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--log", default=None)
+    ap.add_argument("--big", action="store_true", help="shard sizes 65 537 ... 2^20 + 3 instead of 1 ... 32 768 (fewer, shorter sequences)")
     a = ap.parse_args()
     from drone_amd import binding
     from oracle import pyoracle
@@ -266,8 +268,8 @@ def main():
     binding.load()
     pyoracle.lib()
     out = open(a.log, "a") if a.log else sys.stdout
-    res = soak(binding, pyoracle, a.seed, cases=a.cases, minutes=a.minutes, log=out, threads=a.threads)
-    print(f"[soak] PASS seed {res['seed']}: {res['cases']} random call sequences (hover / waypoint / swarm / race: {res['cases_per_task']}), "
+    res = soak(binding, pyoracle, a.seed, cases=a.cases, minutes=a.minutes, log=out, threads=a.threads, big=a.big)
+    print(f"[soak] PASS seed {res['seed']}{' --big' if a.big else ''}: {res['cases']} random call sequences (hover / waypoint / swarm / race: {res['cases_per_task']}), "
           f"{res['env_steps_compared']:.4e} env-steps compared bit for bit in {res['seconds']:.0f} s", file=out, flush=True)
     if a.log:
         out.close()
