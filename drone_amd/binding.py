@@ -157,6 +157,7 @@ class DroneVec:
             self.rewards = torch.zeros(n, dtype=torch.float32, device=dev)
             self.terminals = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.truncations = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._seed = int(seed)
         self._h = self._f["drone_vec_init"](
             _ptr(self.observations), _ptr(self.actions), _ptr(self.rewards), _ptr(self.terminals), _ptr(self.truncations),
             n, seed, C.byref(self.cfg))
@@ -208,6 +209,7 @@ class DroneVec:
 
     # -- the path --
     def reset(self, seed=0):
+        self._seed = int(seed)
         self._f["drone_vec_reset"](self._h, seed)
         self._raise_if_failed()
 
@@ -357,6 +359,45 @@ class DroneVec:
     def set_state(self, rows, first=0):
         rows = np.ascontiguousarray(rows, dtype=abi.state_row_dtype())
         self._check(self._f["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows)))
+
+    # -- checkpoint / resume: everything a run needs to continue bit for bit --
+    _CKPT_CFG_SKIP = ("struct_size", "buffer_kind", "device", "host_pages_exclusive")  # where the buffers live is the resuming process's business
+
+    def save_checkpoint(self, path):
+        """Write the shard's state rows, the vec-level step counter, the seed the RNG streams are keyed on, the env
+        config and the current contents of the five caller buffers to ``path`` (numpy .npz). A handle restored with
+        ``load_checkpoint`` continues exactly like this one: same trajectories, resets, wind, policy draws and logs."""
+        self.sync()
+        cfg = {k: v for k, v in self.cfg.as_dict().items() if k not in self._CKPT_CFG_SKIP}
+        to_np = lambda x: x.cpu().numpy() if _is_torch(x) else np.asarray(x)  # noqa: E731
+        with open(path, "wb") as fh:
+            np.savez(fh, rows=self.get_state(), gstep=np.uint32(self.gstep), seed=np.uint64(self._seed), num_envs=np.int64(self.num_envs),
+                     cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], dtype=np.float64),
+                     observations=to_np(self.observations), actions=to_np(self.actions), rewards=to_np(self.rewards),
+                     terminals=to_np(self.terminals), truncations=to_np(self.truncations))
+
+    def load_checkpoint(self, path):
+        """Restore a ``save_checkpoint`` file into this handle (same num_envs and env config; host or device buffers
+        alike). Refuses a file written under a different config or shard size rather than continuing a different env."""
+        with np.load(path) as z:
+            if int(z["num_envs"]) != self.num_envs:
+                raise ValueError(f"checkpoint holds {int(z['num_envs'])} envs, this handle {self.num_envs}")
+            mine = self.cfg.as_dict()
+            for k, val in zip(z["cfg_keys"].tolist(), z["cfg_vals"].tolist()):
+                if float(mine[k]) != val:
+                    raise ValueError(f"checkpoint was written with {k} = {val}, this handle has {mine[k]}")
+            self.reset(int(z["seed"]))  # re-keys every RNG stream, clears the log planes
+            self.set_state(z["rows"])
+            self.set_gstep(int(z["gstep"]))
+            for name in ("observations", "actions", "rewards", "terminals", "truncations"):
+                dst = getattr(self, name)
+                if _is_torch(dst):
+                    import torch
+
+                    dst.copy_(torch.from_numpy(z[name]).view(dst.dtype) if dst.dtype == torch.bool else torch.from_numpy(z[name]))
+                else:
+                    dst[...] = z[name]
+        self.sync()
 
     def done_list(self):
         ids = np.zeros(self.num_envs, dtype=np.uint32)

@@ -100,5 +100,16 @@ class Drone:
                 infos.append(log)
         return bufs.observations, bufs.rewards, bufs.terminals, bufs.truncations, infos
 
+    def save(self, path):
+        """Checkpoint the env (state, step counter, seed, config, buffer contents): ``DroneVec.save_checkpoint``."""
+        self.vec.save_checkpoint(path)
+
+    def load(self, path):
+        """Resume from ``save``: the env continues bit for bit like the one that wrote the file. Returns the observations."""
+        self.vec.load_checkpoint(path)
+        self.seed = self.vec._seed
+        self.tick = self.vec.gstep
+        return self.observations
+
     def close(self):
         self.vec.close()
