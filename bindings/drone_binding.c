@@ -282,6 +282,7 @@ static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
         int isdev = device_pointer(bufs[i], &d);
         if (isdev < 0) { handle_free(h); return NULL; }
         if (isdev == 2) { /* a DLPack producer: the env consumes its managed tensor and keeps it until close */
+            if (kind == 0) { PyErr_SetString(PyExc_TypeError, "vec_init: buffers must be all host buffers or all device tensors"); handle_free(h); return NULL; }
             int dl_dev = 0;
             if (dl_import(bufs[i], i < 3, need[i], names[i], &h->imported[h->n_imported], &d, &dl_dev) < 0) { handle_free(h); return NULL; }
             h->n_imported++;
@@ -291,7 +292,6 @@ static PyObject* vec_init(PyObject* self, PyObject* args, PyObject* kwargs) {
                 handle_free(h);
                 return NULL;
             }
-            if (kind == 0) { PyErr_SetString(PyExc_TypeError, "vec_init: buffers must be all host buffers or all device tensors"); handle_free(h); return NULL; }
             kind = 1;
             ptr[i] = d;
             continue;
@@ -630,6 +630,30 @@ static PyObject* vec_gstep(PyObject* self, PyObject* args) {
     return PyLong_FromUnsignedLong(drone_vec_gstep(h->v));
 }
 
+/* vec_device(handle) -> HIP device ordinal of the env; vec_sync(handle): wait for the env's stream */
+static PyObject* vec_device(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    return PyLong_FromLong(drone_vec_device(h->v));
+}
+
+static PyObject* vec_sync(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    rc = drone_vec_sync(h->v);
+    Py_END_ALLOW_THREADS
+    if (rc != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); return NULL; }
+    Py_RETURN_NONE;
+}
+
 static PyObject* obs_dim(PyObject* self, PyObject* args) {
     (void)self;
     int task;
@@ -654,6 +678,8 @@ static PyMethodDef methods[] = {
     {"vec_set_stream", vec_set_stream, METH_VARARGS, "vec_set_stream(handle, hip_stream_address)"},
     {"vec_fill_random_actions", vec_fill_random_actions, METH_VARARGS, "vec_fill_random_actions(handle, actions=None, gstep=None)"},
     {"vec_gstep", vec_gstep, METH_VARARGS, "vec_gstep(handle) -> int"},
+    {"vec_device", vec_device, METH_VARARGS, "vec_device(handle) -> HIP device ordinal the env lives on"},
+    {"vec_sync", vec_sync, METH_VARARGS, "vec_sync(handle): wait until everything enqueued on the env's stream has finished"},
     {"obs_dim", obs_dim, METH_VARARGS, "obs_dim(task) -> floats per observation row"},
     {NULL, NULL, 0, NULL}};
 

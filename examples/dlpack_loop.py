@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch  # noqa: E402
 
+from drone_amd import dlpack  # noqa: E402
 from drone_amd import drone_binding as binding  # noqa: E402
 
 
@@ -24,7 +25,7 @@ def main():
     ap.add_argument("--task", type=int, default=binding.TASK_HOVER)
     a = ap.parse_args()
     env = binding.vec_init(None, None, None, None, None, a.envs, 0, task=a.task)
-    obs, act, rew, term, trunc = (torch.from_dlpack(binding.vec_dlpack(env, k)) for k in ("observations", "actions", "rewards", "terminals", "truncations"))
+    obs, act, rew, term, trunc = (torch.from_dlpack(b) for b in dlpack.buffers(env))  # protocol objects over binding.vec_dlpack capsules
     od = binding.obs_dim(a.task)
     policy = torch.nn.Sequential(torch.nn.Linear(od, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4), torch.nn.Tanh()).to(obs.device)
     stream = torch.cuda.Stream()

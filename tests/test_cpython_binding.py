@@ -217,3 +217,27 @@ def test_binding_step_many_matches_oracle(ext, oracle, task, device):
     with pytest.raises(ValueError, match="actions is None"):
         ext.vec_step_repeat(h, 5, None, *blocks)
     ext.vec_close(h)
+
+
+def test_dlpack_argument_checks_need_no_gpu(ext):
+    """The DLPack import path validates the managed tensor before the library (and with it the GPU) is touched."""
+    import torch
+
+    class OnlyDLPack:
+        def __init__(self, t):
+            self._t = t
+
+        def __dlpack__(self, stream=None):
+            return self._t.__dlpack__()
+
+    n = 16
+    cpu = [torch.zeros(n, 20), torch.zeros(n, 4), torch.zeros(n), torch.zeros(n, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8)]
+    with pytest.raises(ValueError, match="not on a ROCm device"):
+        ext.vec_init(*(OnlyDLPack(t) for t in cpu), n, 0)
+    with pytest.raises(TypeError, match="None five times"):
+        ext.vec_init(None, None, None, None, np.zeros(n, np.uint8), n, 0)
+    with pytest.raises(TypeError, match="all host buffers or all device"):
+        ext.vec_init(np.zeros((n, 20), np.float32), *(OnlyDLPack(t) for t in cpu[1:]), n, 0)
+    # a refused producer keeps its memory: the capsule was not consumed
+    assert float(cpu[0].sum()) == 0.0 and cpu[0].data_ptr() != 0
+    assert callable(ext.vec_dlpack)

@@ -250,3 +250,35 @@ def test_c_abi_library_owned_buffers(hip):
     cfg.buffer_kind = abi.BUFFERS_DEVICE
     t = torch.zeros(1024, 20, device="cuda")
     assert not lib.drone_vec_init(C.c_void_p(t.data_ptr()), None, None, None, None, 1024, 3, C.byref(cfg))
+
+
+@pytest.mark.gpu
+def test_protocol_objects_for_newer_consumers(ext, oracle):
+    """drone_amd.dlpack.Buffer: __dlpack__ / __dlpack_device__ over the capsules (consumers that refuse bare capsules)."""
+    import torch
+
+    from drone_amd import dlpack
+
+    n, seed = 2048, 9
+    h = ext.vec_init(None, None, None, None, None, n, seed, task=1)
+    objs = dlpack.buffers(h)
+    assert objs[0].__dlpack_device__() == (10, ext.vec_device(h)) == (10, 0)  # kDLROCM
+    obs, act, rew, term, trunc = (torch.from_dlpack(o) for o in objs)  # torch passes stream= and max_version=
+    assert obs.shape == (n, 20) and act.shape == (n, 4) and term.dtype == torch.uint8 and obs.is_cuda
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(1), threads=8)
+    drive(ext, oracle, h, o, obs, act, rew, term, trunc, 30, seed)
+    side = torch.cuda.Stream()
+    ext.vec_set_stream(h, side.cuda_stream)
+    o.fill_random_actions()
+    act.copy_(torch.from_numpy(o.actions))
+    torch.cuda.synchronize()
+    o.step()
+    ext.vec_step(h)  # asynchronous on `side`
+    again = torch.from_dlpack(dlpack.buffer(h, "observations"))  # the export drains the env's stream for the consumer's
+    assert_bits_equal(o.observations, again.cpu().numpy(), "observations exported right after an asynchronous step")
+    with pytest.raises(ValueError, match="unknown buffer"):
+        dlpack.buffer(h, "nope")
+    ext.vec_sync(h)
+    del obs, act, rew, term, trunc, again
+    gc.collect()
+    ext.vec_close(h)
