@@ -5,7 +5,7 @@
  * side stays C calling HIP through a thin C-ABI".) No HIP headers here: the
  * device is entirely behind the C-ABI.
  *
- *   drone_host [--envs N] [--steps K] [--task 0..3] [--rollout T] [--seed S] [--crc 1]
+ *   drone_host [--envs N] [--steps K] [--task 0..3] [--rollout T] [--seed S] [--crc 1] [--many K] [--fill 0|1]
  *
  * Prints env-steps/s for (a) per-step calls with host buffers — every step
  * pays H2D actions + D2H observations/rewards/flags over PCIe — and (b) the
@@ -58,7 +58,7 @@ static double now_s(void) {
 }
 
 int main(int argc, char** argv) {
-    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0, many = 0;
+    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0, many = 0, fill = 1;
     unsigned long long seed = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--envs")) envs = atoi(argv[i + 1]);
@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--rollout")) rollout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], NULL, 10);
         else if (!strcmp(argv[i], "--crc")) crc_mode = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--fill")) fill = atoi(argv[i + 1]); /* 0: time the env step alone (actions stay as first drawn); 1: a fresh random action batch per step, itself a device round trip */
         else if (!strcmp(argv[i], "--many")) many = atoi(argv[i + 1]); /* K > 0: step through drone_vec_step_many, K env steps per call */
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
@@ -144,13 +145,13 @@ int main(int argc, char** argv) {
     double t0 = now_s();
     long dones = 0;
     for (int t = 0; t < steps; t++) {
-        drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
+        if (fill) drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
         drone_vec_step(v);
         for (int i = 0; i < envs; i += 4096) dones += term[i] | trunc[i]; /* touch the outputs */
     }
     double el = now_s() - t0;
-    printf("{\"mode\": \"per-step host buffers (PCIe inclusive)\", \"envs\": %d, \"steps\": %d, \"env_steps_per_s\": %.4g, \"ms_per_step\": %.4f}\n",
-           envs, steps, (double)envs * steps / el, el * 1e3 / steps);
+    printf("{\"mode\": \"per-step host buffers (PCIe inclusive)\", \"envs\": %d, \"steps\": %d, \"fresh_actions_per_step\": %d, \"transport\": %d, \"env_steps_per_s\": %.4g, \"ms_per_step\": %.4f}\n",
+           envs, steps, fill, drone_vec_host_transport(v), (double)envs * steps / el, el * 1e3 / steps);
 
     /* (a') K env steps per call with every step's outputs (drone_vec_step_many): one launch and one round of copies per K steps */
     if (many > 0) {
