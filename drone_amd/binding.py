@@ -297,10 +297,11 @@ class DroneVec:
 
     @property
     def host_transport(self):
-        """'zero-copy' (the kernel reads / writes the pinned host buffers over PCIe), 'mirror' (device mirrors +
-        copies), or None for device buffers."""
+        """'zero-copy' (the kernel reads / writes the pinned host buffers over PCIe), 'stand-in' (the same through
+        pinned stand-ins the library owns for buffers it may not pin, copied on the host around each step), 'mirror'
+        (device mirrors + DMA copies), or None for device buffers."""
         t = self._f["drone_vec_host_transport"](self._h)
-        return {1: "zero-copy", 0: "mirror"}.get(t)
+        return {1: "zero-copy", 2: "stand-in", 0: "mirror"}.get(t)
 
     def enable_graph_capture(self, on=True):
         """Counters in HBM, advanced by the kernels: a captured step / rollout (torch.cuda.graph) replays correctly."""

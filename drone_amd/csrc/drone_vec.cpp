@@ -102,7 +102,12 @@ struct DroneVec {
     float* d_rew;
     unsigned char* d_term;
     unsigned char* d_trunc;
-    float* m_obs;        // device-visible addresses of the caller's registered host buffers (zero_copy)
+    // zero_copy: pinned + mapped stand-ins, owned here, for the caller buffers that could not be pinned themselves
+    // (slot order: observations, actions, rewards, terminals, truncations; null = the caller's buffer is mapped directly).
+    // The kernel reads / writes the stand-in over PCIe; the host copies between it and the caller's buffer around the step.
+    void* bounce[5];
+    size_t bounce_bytes[5];
+    float* m_obs;        // device-visible addresses of the caller's registered host buffers or of their stand-ins (zero_copy)
     float* m_act;
     float* m_rew;
     unsigned char* m_term;
@@ -235,7 +240,10 @@ bool validate(const DroneConfig* c, int num_envs) {
 }
 
 bool host_to_device_actions(DroneVec* v) {
-    if (v->zero_copy) return true;  // the kernel reads the caller's action buffer itself
+    if (v->zero_copy) {  // the kernel reads the caller's action buffer itself, or its pinned stand-in
+        if (v->bounce[1]) memcpy(v->bounce[1], v->u_act, v->bounce_bytes[1]);
+        return true;
+    }
     HIP_TRY(hipMemcpyAsync(v->d_act, v->u_act, (size_t)v->n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return false);
     return true;
 }
@@ -266,7 +274,14 @@ bool wait_zero_copy(DroneVec* v) {
 }
 
 bool device_to_host_outputs(DroneVec* v) {
-    if (v->zero_copy) return wait_zero_copy(v);  // outputs already landed in the caller's memory: just wait for the kernel
+    if (v->zero_copy) {  // outputs already landed in the caller's memory (or its stand-ins): just wait for the kernel
+        if (!wait_zero_copy(v)) return false;
+        if (v->bounce[0]) memcpy(v->u_obs, v->bounce[0], v->bounce_bytes[0]);
+        if (v->bounce[2]) memcpy(v->u_rew, v->bounce[2], v->bounce_bytes[2]);
+        if (v->bounce[3]) memcpy(v->u_term, v->bounce[3], v->bounce_bytes[3]);
+        if (v->bounce[4]) memcpy(v->u_trunc, v->bounce[4], v->bounce_bytes[4]);
+        return true;
+    }
     const size_t n = (size_t)v->n;
     HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipMemcpyAsync(v->u_rew, v->d_rew, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
@@ -312,8 +327,17 @@ void unpin_if_rebound(DroneVec* v, int slot, const void* now) {
     }
 }
 
+void drop_bounce(DroneVec* v) {
+    for (int k = 0; k < 5; k++) {
+        if (v->bounce[k]) (void)hipHostFree(v->bounce[k]);
+        v->bounce[k] = nullptr;
+        v->bounce_bytes[k] = 0;
+    }
+}
+
 void leave_zero_copy(DroneVec* v) {
     v->zero_copy = false;
+    drop_bounce(v);  // (the caller syncs the stream before anything reuses the mirrors: Entry-guarded calls only)
     v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
 }
 
@@ -529,7 +553,13 @@ int drone_vec_bytes_per_env_step(const DroneVec* v) {
     return 16 * (planes_read + planes_written) + 16 + 4 * drone_obs_dim(task) + 4 + 2;
 }
 
-int drone_vec_host_transport(const DroneVec* v) { return !v ? -1 : !v->host_buffers ? -1 : v->zero_copy ? 1 : 0; }
+int drone_vec_host_transport(const DroneVec* v) {
+    if (!v || !v->host_buffers) return -1;
+    if (!v->zero_copy) return 0;
+    for (int k = 0; k < 5; k++)
+        if (v->bounce[k]) return 2;
+    return 1;
+}
 
 int drone_vec_buffers(const DroneVec* v, float** observations, float** actions, float** rewards, unsigned char** terminals, unsigned char** truncations) {
     if (!v) { set_err("NULL handle"); return -1; }
@@ -617,19 +647,37 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         INIT_TRY(hipMalloc((void**)&v->d_rew, n * sizeof(float)));
         INIT_TRY(hipMalloc((void**)&v->d_term, n));
         INIT_TRY(hipMalloc((void**)&v->d_trunc, n));
-        bool all_reg = true;
-        all_reg = pin_caller_buffer(v, 0, observations, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float)) && all_reg;
-        all_reg = pin_caller_buffer(v, 1, actions, n * DRONE_ACT_DIM * sizeof(float)) && all_reg;
-        all_reg = pin_caller_buffer(v, 2, rewards, n * sizeof(float)) && all_reg;
-        all_reg = pin_caller_buffer(v, 3, terminals, n) && all_reg;
-        all_reg = pin_caller_buffer(v, 4, truncations, n) && all_reg;
+        void* const host[5] = {observations, actions, rewards, terminals, truncations};
+        const size_t bytes[5] = {n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float), n * DRONE_ACT_DIM * sizeof(float), n * sizeof(float), n, n};
+        bool pinned[5];
+        size_t unpinned_bytes = 0;
+        for (int k = 0; k < 5; k++) {
+            pinned[k] = pin_caller_buffer(v, k, host[k], bytes[k]);
+            if (!pinned[k]) unpinned_bytes += bytes[k];
+        }
         v->dv.obs = v->d_obs; v->dv.act = v->d_act; v->dv.rew = v->d_rew; v->dv.term = v->d_term; v->dv.trunc = v->d_trunc;
-        if (all_reg && want_zero_copy(num_envs)) {
-            v->m_obs = (float*)mapped_ptr(observations);
-            v->m_act = (float*)mapped_ptr(actions);
-            v->m_rew = (float*)mapped_ptr(rewards);
-            v->m_term = (unsigned char*)mapped_ptr(terminals);
-            v->m_trunc = (unsigned char*)mapped_ptr(truncations);
+        // Buffers that cannot be pinned (a worker's unaligned slices of a shared-memory block: the one-byte flag slices
+        // practically always) get pinned stand-ins owned here, as long as copying them on the host is cheaper than the
+        // mirror transport's DMA copies: up to DRONE_HOST_BOUNCE_MAX_BYTES in total (default 1 MiB; 0 = never).
+        const char* bm = getenv("DRONE_HOST_BOUNCE_MAX_BYTES");
+        const size_t bounce_max = (bm && *bm) ? (size_t)atoll(bm) : ((size_t)1 << 20);
+        if (want_zero_copy(num_envs) && unpinned_bytes <= bounce_max) {
+            void* mapped[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            bool have_all = true;
+            for (int k = 0; k < 5 && have_all; k++) {
+                if (!pinned[k]) {
+                    if (hipHostMalloc(&v->bounce[k], bytes[k], hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); v->bounce[k] = nullptr; have_all = false; break; }
+                    v->bounce_bytes[k] = bytes[k];
+                    memset(v->bounce[k], 0, bytes[k]);
+                }
+                mapped[k] = mapped_ptr(v->bounce[k] ? v->bounce[k] : host[k]);
+                have_all = mapped[k] != nullptr;
+            }
+            v->m_obs = (float*)mapped[0];
+            v->m_act = (float*)mapped[1];
+            v->m_rew = (float*)mapped[2];
+            v->m_term = (unsigned char*)mapped[3];
+            v->m_trunc = (unsigned char*)mapped[4];
             const bool ok = v->m_obs && v->m_act && v->m_rew && v->m_term && v->m_trunc &&
                             !(reinterpret_cast<uintptr_t>(v->m_obs) & 15u) && !(reinterpret_cast<uintptr_t>(v->m_act) & 15u) &&
                             !(reinterpret_cast<uintptr_t>(v->m_rew) & 3u);
@@ -648,6 +696,8 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
                     }
                 }
                 v->dv.obs = v->m_obs; v->dv.act = v->m_act; v->dv.rew = v->m_rew; v->dv.term = v->m_term; v->dv.trunc = v->m_trunc;
+            } else {
+                drop_bounce(v);  // mirror transport after all
             }
         }
     } else {
@@ -871,6 +921,7 @@ void drone_vec_close(DroneVec* v) {
     (void)hipFree(v->d_partials);
     if (v->h_partials) (void)hipHostFree(v->h_partials);
     if (v->h_flag) (void)hipHostFree(const_cast<uint32_t*>(v->h_flag));
+    drop_bounce(v);
     (void)hipFree(v->dv.done_ids);
     (void)hipFree(v->dv.done_count);
     (void)hipFree(v->many_ids);
@@ -918,7 +969,9 @@ int drone_vec_bind_actions(DroneVec* v, float* actions) {
     if (!in) return -1;
     if (!actions) { set_err("bind_actions: NULL argument"); return -1; }
     if (v->host_buffers) {
-        if (v->zero_copy && actions != v->u_act) leave_zero_copy(v);  // an unregistered buffer: back to the mirror transport
+        // an unregistered buffer: back to the mirror transport — unless the actions already go through a stand-in, which
+        // takes them from wherever the caller keeps them
+        if (v->zero_copy && actions != v->u_act && !v->bounce[1]) leave_zero_copy(v);
         unpin_if_rebound(v, 1, actions);
         v->u_act = actions;  // copied (pageable unless the caller pinned it) at the next step
     } else {
@@ -942,8 +995,10 @@ int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, uns
     }
     // host mode: the device mirrors stay; the next step copies out to the new addresses
     // (pageable unless the caller pinned them)
-    if (v->host_buffers && v->zero_copy && (observations != v->u_obs || rewards != v->u_rew || terminals != v->u_term || truncations != v->u_trunc))
-        leave_zero_copy(v);
+    if (v->host_buffers && v->zero_copy &&
+        ((observations != v->u_obs && !v->bounce[0]) || (rewards != v->u_rew && !v->bounce[2]) || (terminals != v->u_term && !v->bounce[3]) ||
+         (truncations != v->u_trunc && !v->bounce[4])))
+        leave_zero_copy(v);  // a directly mapped buffer was replaced (stand-ins deliver to wherever the caller points)
     if (v->host_buffers) {
         unpin_if_rebound(v, 0, observations);
         unpin_if_rebound(v, 2, rewards);

@@ -5,7 +5,7 @@
  * side stays C calling HIP through a thin C-ABI".) No HIP headers here: the
  * device is entirely behind the C-ABI.
  *
- *   drone_host [--envs N] [--steps K] [--task 0..3] [--rollout T] [--seed S] [--crc 1] [--many K] [--fill 0|1]
+ *   drone_host [--envs N] [--steps K] [--task 0..3] [--rollout T] [--seed S] [--crc 1] [--many K] [--fill 0|1] [--heap 0|1]
  *
  * Prints env-steps/s for (a) per-step calls with host buffers — every step
  * pays H2D actions + D2H observations/rewards/flags over PCIe — and (b) the
@@ -51,6 +51,13 @@ static uint32_t crc32_update(uint32_t crc, const void* buf, size_t len) {
     return ~crc;
 }
 
+/* The opposite: a zeroed buffer that does NOT own its pages (64 bytes into a malloc block), like a vec-env worker's
+ * unaligned slice of a shared block: the library may not pin it (--heap 1). Never freed: the process is short-lived. */
+static void* heap_alloc(size_t bytes) {
+    char* p = (char*)calloc(bytes + 128, 1);
+    return p ? p + 64 : NULL;
+}
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -58,7 +65,7 @@ static double now_s(void) {
 }
 
 int main(int argc, char** argv) {
-    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0, many = 0, fill = 1;
+    int envs = 65536, steps = 1000, task = DRONE_TASK_HOVER, rollout = 128, crc_mode = 0, many = 0, fill = 1, heap = 0;
     unsigned long long seed = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--envs")) envs = atoi(argv[i + 1]);
@@ -68,6 +75,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--seed")) seed = strtoull(argv[i + 1], NULL, 10);
         else if (!strcmp(argv[i], "--crc")) crc_mode = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--fill")) fill = atoi(argv[i + 1]); /* 0: time the env step alone (actions stay as first drawn); 1: a fresh random action batch per step, itself a device round trip */
+        else if (!strcmp(argv[i], "--heap")) heap = atoi(argv[i + 1]); /* 1: buffers that share their pages with the heap (never pinned by the library) */
         else if (!strcmp(argv[i], "--many")) many = atoi(argv[i + 1]); /* K > 0: step through drone_vec_step_many, K env steps per call */
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
@@ -78,17 +86,18 @@ int main(int argc, char** argv) {
     if (many < 0 || many > 4096) { fprintf(stderr, "--many must be in [0, 4096]\n"); return 2; }
     if (envs <= 0 || steps <= 0 || rollout <= 0) { fprintf(stderr, "--envs, --steps and --rollout must be positive\n"); return 2; }
     const size_t obs_dim = (size_t)drone_obs_dim(task); /* 20, or 24 for the swarm and race tasks */
-    float* obs = (float*)page_alloc(sizeof(float) * (size_t)envs * obs_dim);
-    float* act = (float*)page_alloc(sizeof(float) * (size_t)envs * DRONE_ACT_DIM);
-    float* rew = (float*)page_alloc(sizeof(float) * (size_t)envs);
-    unsigned char* term = (unsigned char*)page_alloc((size_t)envs);
-    unsigned char* trunc = (unsigned char*)page_alloc((size_t)envs);
+    void* (*const alloc)(size_t) = heap ? heap_alloc : page_alloc;
+    float* obs = (float*)alloc(sizeof(float) * (size_t)envs * obs_dim);
+    float* act = (float*)alloc(sizeof(float) * (size_t)envs * DRONE_ACT_DIM);
+    float* rew = (float*)alloc(sizeof(float) * (size_t)envs);
+    unsigned char* term = (unsigned char*)alloc((size_t)envs);
+    unsigned char* trunc = (unsigned char*)alloc((size_t)envs);
     if (!obs || !act || !rew || !term || !trunc) { fprintf(stderr, "out of memory\n"); return 1; }
 
     DroneConfig cfg;
     drone_config_default(&cfg, task);
     cfg.buffer_kind = DRONE_BUFFERS_HOST;
-    cfg.host_pages_exclusive = 1; /* page_alloc: every buffer owns its pages */
+    cfg.host_pages_exclusive = heap ? 0 : 1; /* page_alloc: every buffer owns its pages */
     DroneVec* v = drone_vec_init(obs, act, rew, term, trunc, envs, seed, &cfg);
     if (!v) { fprintf(stderr, "drone_vec_init failed: %s\n", drone_last_error()); return 1; }
     drone_vec_reset(v, seed);
@@ -136,7 +145,7 @@ int main(int argc, char** argv) {
         drone_vec_log(v, &lg);
         printf("{\"mode\": \"crc\", \"task\": %d, \"envs\": %d, \"steps\": %d, \"steps_per_call\": %d, \"crc32\": %u, \"episodes\": %.0f}\n", task, envs, steps, many > 0 ? many : 1, crc, lg.n);
         drone_vec_close(v);
-        free(obs); free(act); free(rew); free(term); free(trunc);
+        if (!heap) { free(obs); free(act); free(rew); free(term); free(trunc); }
         return 0;
     }
 
@@ -180,7 +189,7 @@ int main(int argc, char** argv) {
            log.n, log.episode_return, log.episode_length, log.score, log.oob, dones);
     if (drone_vec_status(v)) { fprintf(stderr, "a call on the handle failed: %s\n", drone_vec_status_message(v)); return 1; }
     drone_vec_close(v);
-    free(obs); free(act); free(rew); free(term); free(trunc);
+    if (!heap) { free(obs); free(act); free(rew); free(term); free(trunc); }
     free(m_act); free(m_obs); free(m_rew); free(m_term); free(m_trunc);
     return 0;
 }

@@ -38,7 +38,7 @@ extern "C" {
 #define DRONE_TASK_SWARM 2    /* agents_per_env drones per env, coupled by a nearest-neighbour term (SPEC.md §10) */
 #define DRONE_TASK_RACE 3     /* fly through a sequence of ring gates (SPEC.md §11) */
 
-#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory. Buffers that own their pages (see host_pages_exclusive) are pinned + mapped and the kernel accesses them over PCIe; any others go through H2D, kernel, D2H copies; step ends with a sync */
+#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory. Buffers that own their pages (see host_pages_exclusive) are pinned + mapped and the kernel accesses them over PCIe; others get pinned stand-ins (small shards) or go through H2D, kernel, D2H copies; step ends with a sync */
 #define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
 
 /* Env kwargs. Fill with drone_config_default() first, then override. */
@@ -104,8 +104,11 @@ int drone_device_count(void);
  * 262 when the handle uses the derived-target layout; waypoint / race 310; swarm 294 / 278) — what bench.py's roofline uses. */
 int drone_vec_bytes_per_env_step(const DroneVec* v);
 
-/* 1 if host-buffer steps of this handle run zero-copy (kernel reads / writes the caller's pinned buffers over PCIe),
- * 0 if they go through device mirrors and copies; -1 for device-buffer handles. */
+/* How host-buffer steps of this handle move their data: 1 = zero-copy (the kernel reads / writes the caller's pinned
+ * buffers over PCIe); 2 = zero-copy through pinned stand-ins the library owns for those of the five buffers that could
+ * not be pinned themselves, copied to / from the caller's memory on the host around each step (small shards only:
+ * DRONE_HOST_BOUNCE_MAX_BYTES, default 1 MiB of such buffers); 0 = device mirrors and DMA copies; -1 for device-buffer
+ * handles. */
 int drone_vec_host_transport(const DroneVec* v);
 
 /* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM and DRONE_TASK_RACE. */

@@ -321,31 +321,62 @@ def test_rebinding_from_a_second_thread_while_another_handle_steps(oracle, hip):
     assert not errs, errs
 
 
-def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip):
+def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip, monkeypatch):
     """Host buffers are registered (zero-copy transport) only when their pages are provably theirs; anything else is
-    copied and never registered. All three cases step bit-exactly."""
+    never registered: the kernel gets pinned stand-ins owned by the library (small shards) or device mirrors. All cases
+    step bit-exactly."""
     n, seed = 4096, 5  # 4096 envs: every buffer is a whole number of pages
     mk = lambda alloc: (alloc((n, 20), np.float32), alloc((n, 4), np.float32), alloc((n,), np.float32), alloc((n,), np.uint8), alloc((n,), np.uint8))
-    cases = [("binding's own page buffers", None, "zero-copy"),
-             ("caller's heap arrays (np.zeros): share pages with other allocations", mk(lambda s, d: np.zeros(s, d)), "mirror"),
-             ("caller's page-aligned whole-page arrays, no flag", mk(hip.page_buffer), "zero-copy")]
-    for what, bufs, want in cases:
+    heap = lambda s, d: np.zeros(s, d)
+    # (what, buffers, transport, stand-in budget, transport after the ACTION buffer is rebound to a fresh heap array)
+    cases = [("binding's own page buffers", None, "zero-copy", None, "mirror"),
+             ("caller's heap arrays (np.zeros): share pages with other allocations", mk(heap), "stand-in", None, "stand-in"),
+             ("the same with stand-ins turned off", mk(heap), "mirror", "0", "mirror"),
+             ("the same with a stand-in budget below this shard's 408 KiB", mk(heap), "mirror", "300000", "mirror"),
+             ("a PufferLib-style worker: page-owning observations / actions / rewards, heap flag slices",
+              (hip.page_buffer((n, 20), np.float32), hip.page_buffer((n, 4), np.float32), hip.page_buffer((n,), np.float32), np.zeros(n + 64, np.uint8)[64:], np.zeros(n + 64, np.uint8)[64:]),
+              "stand-in", None, "mirror"),  # its action buffer was mapped directly: replacing it ends the zero-copy transport
+             ("caller's page-aligned whole-page arrays, no flag", mk(hip.page_buffer), "zero-copy", None, "mirror")]
+    for what, bufs, want, budget, after_rebind in cases:
+        if budget is None:
+            monkeypatch.delenv("DRONE_HOST_BOUNCE_MAX_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("DRONE_HOST_BOUNCE_MAX_BYTES", budget)
         o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(1, horizon=25), threads=4)
         h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25), buffers=bufs) if bufs is not None else hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25))
         assert h.host_transport == want, what
         o.reset(seed)
         h.reset(seed)
+        assert_outputs_equal(o, h, what + ": reset")
         for t in range(60):
             o.fill_random_actions()
             h.actions[:] = o.actions
             o.step()
             h.step()
-        assert_outputs_equal(o, h, what)
+            assert_outputs_equal(o, h, f"{what}: step {t}")
+        o.rollout(7)
+        h.rollout(7)
+        assert_outputs_equal(o, h, what + ": rollout")
+        # a stand-in takes the actions from wherever the caller keeps them: rebinding such a buffer keeps the transport
+        act2 = np.zeros((n, 4), np.float32)
+        h.bind_actions(act2)
+        o.fill_random_actions()
+        act2[:] = o.actions
+        o.step()
+        h.step()
+        assert_outputs_equal(o, h, what + ": after rebinding the actions")
+        assert h.host_transport == after_rebind, what + ": transport after rebinding the actions"
         h.close()
+    monkeypatch.delenv("DRONE_HOST_BOUNCE_MAX_BYTES", raising=False)
     # a ragged env count with caller heap arrays that happen to be page-aligned at the start only: not pinned without the flag
     m = 1000
     base = hip.page_buffer((m, 20), np.float32)
     h = hip.DroneVec(m, seed=seed, cfg=hip.default_config(0), buffers=(base, np.zeros((m, 4), np.float32), np.zeros(m, np.float32), np.zeros(m, np.uint8), np.zeros(m, np.uint8)))
+    assert h.host_transport == "stand-in"  # nothing of the caller's was registered
+    h.close()
+    # a shard whose unpinnable buffers exceed the stand-in budget takes the mirror transport
+    big = 16384
+    h = hip.DroneVec(big, seed=seed, cfg=hip.default_config(0), buffers=(np.zeros((big, 20), np.float32), np.zeros((big, 4), np.float32), np.zeros(big, np.float32), np.zeros(big, np.uint8), np.zeros(big, np.uint8)))
     assert h.host_transport == "mirror"
     h.close()
 
