@@ -1013,7 +1013,12 @@ int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep) {
     Entry in(v);
     if (!in) return -1;
     if (!actions) { set_err("fill_random_actions: NULL buffer"); return -1; }
-    if (v->host_buffers) {
+    if (v->host_buffers && v->zero_copy && actions == v->u_act) {
+        // the bound action buffer is mapped (itself or through its stand-in): the kernel writes it over PCIe, no copy command
+        HIP_TRY(launch_fill_actions(v->dv, v->m_act, gstep, v->stream), return -1);
+        if (!wait_zero_copy(v)) return -1;
+        if (v->bounce[1]) memcpy(v->u_act, v->bounce[1], v->bounce_bytes[1]);
+    } else if (v->host_buffers) {
         // generate on the device into the action mirror, then hand the host its copy
         HIP_TRY(launch_fill_actions(v->dv, v->d_act, gstep, v->stream), return -1);
         HIP_TRY(hipMemcpyAsync(actions, v->d_act, (size_t)v->n * DRONE_ACT_DIM * sizeof(float), hipMemcpyDeviceToHost, v->stream), return -1);
