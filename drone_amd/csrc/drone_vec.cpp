@@ -292,13 +292,16 @@ bool device_to_host_outputs(DroneVec* v) {
 }
 
 // Host-buffer mode has two transports. Mirror: actions H2D, kernel on device
-// mirrors, four D2H copies. Zero-copy: the caller's (registered) buffers are
-// mapped into the device address space and the kernel loads the actions and
-// stores its outputs through PCIe itself — no copy commands at all, which is
-// what small vec-envs (launch/copy-latency bound) want. Chosen at init:
-// zero-copy when every buffer could be registered, mapped and is 16-B aligned
-// and the shard is at most DRONE_ZERO_COPY_MAX_ENVS envs (default from
-// measurement); the environment variable DRONE_HOST_ZEROCOPY=0/1 forces it.
+// mirrors, four D2H copies. Zero-copy: host memory is mapped into the device
+// address space and the kernel loads the actions and stores its outputs through
+// PCIe itself — no copy commands at all, which is what small vec-envs
+// (launch / copy-latency bound) want. What gets mapped is, per buffer, the
+// caller's own memory where it may be pinned (pin_caller_buffer) and a pinned
+// stand-in owned by the handle where it may not (DroneVec::bounce: copied to /
+// from the caller's memory on the host around the step, so only while that is
+// cheaper than the mirror's DMA copies). Chosen at init: zero-copy when every
+// buffer is mapped one way or the other and 16-B aligned and the shard is at
+// most DRONE_ZERO_COPY_MAX_ENVS envs; DRONE_HOST_ZEROCOPY=0/1 forces it.
 constexpr int kZeroCopyMaxEnvsDefault = 1 << 30;
 
 bool want_zero_copy(int num_envs) {
