@@ -364,6 +364,33 @@ static PyObject* vec_step(PyObject* self, PyObject* args) {
     Py_RETURN_NONE;
 }
 
+/* vec_send(handle) / vec_recv(handle): vec_step in two halves (drone_vec_step_send / drone_vec_step_recv) */
+static PyObject* vec_send(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    Py_BEGIN_ALLOW_THREADS
+    drone_vec_step_send(h->v);
+    Py_END_ALLOW_THREADS
+    if (raise_if_failed(h) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
+static PyObject* vec_recv(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    Py_BEGIN_ALLOW_THREADS
+    drone_vec_step_recv(h->v);
+    Py_END_ALLOW_THREADS
+    if (raise_if_failed(h) < 0) return NULL;
+    Py_RETURN_NONE;
+}
+
 /* vec_rollout(handle, horizon): fused rollout under the device-side random policy (SPEC.md §9) */
 static PyObject* vec_rollout(PyObject* self, PyObject* args) {
     (void)self;
@@ -666,6 +693,8 @@ static PyMethodDef methods[] = {
      "vec_init(observations, actions, rewards, terminals, truncations, num_envs, seed, **env_kwargs) -> handle"},
     {"vec_reset", vec_reset, METH_VARARGS, "vec_reset(handle, seed=0)"},
     {"vec_step", vec_step, METH_VARARGS, "vec_step(handle): read actions, advance every env, overwrite the output buffers"},
+    {"vec_send", vec_send, METH_VARARGS, "vec_send(handle): first half of vec_step — read the actions, enqueue the step, return without waiting"},
+    {"vec_recv", vec_recv, METH_VARARGS, "vec_recv(handle): second half — wait for the sent step, outputs are in the buffers"},
     {"vec_rollout", vec_rollout, METH_VARARGS, "vec_rollout(handle, horizon): fused rollout under the device-side random policy"},
     {"vec_step_many", vec_step_many, METH_VARARGS,
      "vec_step_many(handle, k_steps, actions | None, observations, rewards, terminals, truncations): K env steps in one launch, every step's outputs in K-major blocks"},

@@ -95,6 +95,8 @@ SYMBOLS = {
     "drone_vec_init": (_P, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(DroneConfig)]),
     "drone_vec_reset": (None, [_P, C.c_uint64]),
     "drone_vec_step": (None, [_P]),
+    "drone_vec_step_send": (None, [_P]),
+    "drone_vec_step_recv": (None, [_P]),
     "drone_vec_rollout": (None, [_P, C.c_int]),
     "drone_vec_step_many": (None, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "drone_vec_step_repeat": (None, [_P, C.c_int, _P, _P, _P, _P, _P]),

@@ -218,6 +218,18 @@ class DroneVec:
         if self._status(self._h):
             self._raise_if_failed()
 
+    def step_send(self):
+        """First half of ``step``: read the actions, enqueue the step; returns without waiting (``drone_vec_step_send``)."""
+        self._f["drone_vec_step_send"](self._h)
+        if self._status(self._h):
+            self._raise_if_failed()
+
+    def step_recv(self):
+        """Second half: wait for the sent step and deliver its outputs into the buffers (``drone_vec_step_recv``)."""
+        self._f["drone_vec_step_recv"](self._h)
+        if self._status(self._h):
+            self._raise_if_failed()
+
     def rollout(self, horizon):
         self._f["drone_vec_rollout"](self._h, int(horizon))
         self._raise_if_failed()

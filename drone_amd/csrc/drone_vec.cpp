@@ -97,6 +97,8 @@ struct DroneVec {
     volatile uint32_t* h_flag;  // pinned + mapped
     void* d_flag;               // its device address
     uint32_t flag_seq;
+    bool flag_posted;           // the current flag_seq is already on the stream (drone_vec_step_send)
+    bool pending;               // a step was sent and not yet received
     float* d_obs;        // host-buffer handles: device mirrors; device handles: the library-owned buffers, if any
     float* d_act;
     float* d_rew;
@@ -255,25 +257,49 @@ bool host_to_device_actions(DroneVec* v) {
 // matters — or a fault, which only the runtime can report) falls back to hipStreamSynchronize. DRONE_HOST_SPIN=0 turns
 // the flag off. Measured with host/drone_host --fill 0 on one box: 15.4 -> 13.2 us per step at 256 envs, 16.7 -> 15.1 at
 // 1 024, 22.8 -> 19.6 at 4 096, 43.3 -> 41.1 at 16 384, no difference from 65 536 on (the step is PCIe-bound there).
+// puts the next sequence number on the stream, behind everything enqueued so far
+void post_flag(DroneVec* v) {
+    v->flag_posted = false;
+    if (!v->h_flag) return;
+    const uint32_t seq = v->flag_seq + 1u;
+    if (hipStreamWriteValue32(v->stream, v->d_flag, seq, 0) == hipSuccess) {
+        v->flag_seq = seq;
+        v->flag_posted = true;
+    } else {
+        (void)hipGetLastError();
+    }
+}
+
 bool wait_zero_copy(DroneVec* v) {
-    if (v->h_flag) {
-        const uint32_t seq = ++v->flag_seq;
-        if (hipStreamWriteValue32(v->stream, v->d_flag, seq, 0) == hipSuccess) {
-            for (uint32_t spins = 0; spins < (1u << 16); spins++) {
-                if (__atomic_load_n(v->h_flag, __ATOMIC_ACQUIRE) == seq) return true;
+    if (!v->flag_posted) post_flag(v);
+    if (v->flag_posted) {
+        v->flag_posted = false;
+        const uint32_t seq = v->flag_seq;
+        for (uint32_t spins = 0; spins < (1u << 16); spins++) {
+            if (__atomic_load_n(v->h_flag, __ATOMIC_ACQUIRE) == seq) return true;
 #if defined(__x86_64__) || defined(__i386__)
-                __builtin_ia32_pause();
+            __builtin_ia32_pause();
 #endif
-            }
-        } else {
-            (void)hipGetLastError();
         }
     }
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
     return true;
 }
 
-bool device_to_host_outputs(DroneVec* v) {
+// The two halves of handing a host caller its outputs: what can be put on the stream right behind the kernel (the
+// completion flag, or the mirror transport's D2H copies), and the wait plus whatever the host has to copy itself.
+// drone_vec_step_send / drone_vec_step_recv run them apart; every synchronous path call runs them back to back.
+bool enqueue_host_outputs(DroneVec* v) {
+    if (v->zero_copy) { post_flag(v); return true; }
+    const size_t n = (size_t)v->n;
+    HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_rew, v->d_rew, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_term, v->d_term, n, hipMemcpyDeviceToHost, v->stream), return false);
+    HIP_TRY(hipMemcpyAsync(v->u_trunc, v->d_trunc, n, hipMemcpyDeviceToHost, v->stream), return false);
+    return true;
+}
+
+bool finish_host_outputs(DroneVec* v) {
     if (v->zero_copy) {  // outputs already landed in the caller's memory (or its stand-ins): just wait for the kernel
         if (!wait_zero_copy(v)) return false;
         if (v->bounce[0]) memcpy(v->u_obs, v->bounce[0], v->bounce_bytes[0]);
@@ -282,13 +308,17 @@ bool device_to_host_outputs(DroneVec* v) {
         if (v->bounce[4]) memcpy(v->u_trunc, v->bounce[4], v->bounce_bytes[4]);
         return true;
     }
-    const size_t n = (size_t)v->n;
-    HIP_TRY(hipMemcpyAsync(v->u_obs, v->d_obs, n * (size_t)drone_obs_dim(v->cfg.task) * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
-    HIP_TRY(hipMemcpyAsync(v->u_rew, v->d_rew, n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return false);
-    HIP_TRY(hipMemcpyAsync(v->u_term, v->d_term, n, hipMemcpyDeviceToHost, v->stream), return false);
-    HIP_TRY(hipMemcpyAsync(v->u_trunc, v->d_trunc, n, hipMemcpyDeviceToHost, v->stream), return false);
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
     return true;
+}
+
+bool device_to_host_outputs(DroneVec* v) { return enqueue_host_outputs(v) && finish_host_outputs(v); }
+
+// every path / plumbing call except drone_vec_step_recv and close: not while a sent step is in flight
+bool idle(DroneVec* v, const char* what) {
+    if (!v->pending) return true;
+    set_err("%s: a step sent with drone_vec_step_send has not been received (drone_vec_step_recv)", what);
+    return false;
 }
 
 // Host-buffer mode has two transports. Mirror: actions H2D, kernel on device
@@ -760,7 +790,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
 
 void drone_vec_reset(DroneVec* v, uint64_t seed) {
     Entry in(v);
-    if (!in) return;
+    if (!in || !idle(v, "reset")) return;
     v->seed = seed;
     v->gstep = 0;
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
@@ -771,21 +801,41 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
-void drone_vec_step(DroneVec* v) {
-    Entry in(v);
-    if (!in) return;
-    if (v->host_buffers && !host_to_device_actions(v)) return;
-    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream), return);
+namespace {
+bool step_send_impl(DroneVec* v) {
+    if (v->host_buffers && !host_to_device_actions(v)) return false;
+    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream), return false);
     v->gstep += 1;
     v->step_launches += 1;
     v->list_valid = true;
     v->many_k = 0;
-    if (v->host_buffers) device_to_host_outputs(v);
+    return !v->host_buffers || enqueue_host_outputs(v);
+}
+}  // namespace
+
+void drone_vec_step(DroneVec* v) {
+    Entry in(v);
+    if (!in || !idle(v, "step")) return;
+    if (step_send_impl(v) && v->host_buffers) finish_host_outputs(v);
+}
+
+void drone_vec_step_send(DroneVec* v) {
+    Entry in(v);
+    if (!in || !idle(v, "step_send")) return;
+    if (step_send_impl(v)) v->pending = true;
+}
+
+void drone_vec_step_recv(DroneVec* v) {
+    Entry in(v);
+    if (!in) return;
+    if (!v->pending) { set_err("step_recv: no step was sent (drone_vec_step_send)"); return; }
+    v->pending = false;
+    if (v->host_buffers) finish_host_outputs(v);
 }
 
 void drone_vec_rollout(DroneVec* v, int horizon) {
     Entry in(v);
-    if (!in) return;
+    if (!in || !idle(v, "rollout")) return;
     if (horizon <= 0) { set_err("rollout: horizon must be positive, got %d", horizon); return; }
     HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream), return);
     v->gstep += (uint32_t)horizon;
@@ -847,7 +897,7 @@ namespace {
 void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat, float* observations, float* rewards,
                     unsigned char* terminals, unsigned char* truncations) {
     Entry in(v);
-    if (!in) return;
+    if (!in || !idle(v, "step_many")) return;
     if (k_steps < 1) { set_err("step_many: k_steps must be positive, got %d", k_steps); return; }
     if (!observations || !rewards || !terminals || !truncations) { set_err("step_many: NULL output block"); return; }
     const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task), K = (size_t)k_steps;
@@ -886,7 +936,7 @@ void drone_vec_log(DroneVec* v, DroneLog* out) {
     if (!out) return;
     memset(out, 0, sizeof(*out));
     Entry in(v);
-    if (!in) return;
+    if (!in || !idle(v, "log")) return;
     int grid = 0;
     HIP_TRY(launch_log_reduce(v->dv, v->d_partials, kLogMaxGrid, &grid, v->stream), return);
     HIP_TRY(hipMemcpyAsync(v->h_partials, v->d_partials, sizeof(double) * 6 * grid, hipMemcpyDeviceToHost, v->stream), return);
@@ -950,7 +1000,7 @@ int drone_vec_set_stream(DroneVec* v, void* hip_stream) {
     if (!v) return -1;
     if ((hipStream_t)hip_stream == v->stream && !v->own_stream) return 0;  // cheap to call every step
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "set_stream")) return -1;
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);
     if (v->own_stream && v->stream) (void)hipStreamDestroy(v->stream);
     v->stream = (hipStream_t)hip_stream;
@@ -969,7 +1019,7 @@ int drone_vec_sync(DroneVec* v) {
 // handle's device, not whatever device the calling thread has current) and a failure sticks to the handle.
 int drone_vec_bind_actions(DroneVec* v, float* actions) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "bind_actions")) return -1;
     if (!actions) { set_err("bind_actions: NULL argument"); return -1; }
     if (v->host_buffers) {
         // an unregistered buffer: back to the mirror transport — unless the actions already go through a stand-in, which
@@ -987,7 +1037,7 @@ int drone_vec_bind_actions(DroneVec* v, float* actions) {
 
 int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, unsigned char* terminals, unsigned char* truncations) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "bind_outputs")) return -1;
     if (!observations || !rewards || !terminals || !truncations) { set_err("bind_outputs: NULL argument"); return -1; }
     if (!v->host_buffers) {
         if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
@@ -1014,7 +1064,7 @@ int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, uns
 
 int drone_vec_fill_random_actions(DroneVec* v, float* actions, uint32_t gstep) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "fill_random_actions")) return -1;
     if (!actions) { set_err("fill_random_actions: NULL buffer"); return -1; }
     if (v->host_buffers && v->zero_copy && actions == v->u_act) {
         // the bound action buffer is mapped (itself or through its stand-in): the kernel writes it over PCIe, no copy command
@@ -1044,7 +1094,7 @@ uint32_t drone_vec_gstep(const DroneVec* v) {
 
 int drone_vec_set_gstep(DroneVec* v, uint32_t gstep) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "set_gstep")) return -1;
     if (!pull_counters(v)) return -1;  // keep the device's step-launch count
     v->gstep = gstep;
     v->list_valid = false;
@@ -1053,7 +1103,7 @@ int drone_vec_set_gstep(DroneVec* v, uint32_t gstep) {
 
 int drone_vec_enable_graph_capture(DroneVec* v, int on) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "enable_graph_capture")) return -1;
     if (v->host_buffers) { set_err("graph-safe stepping needs device buffers (host-buffer steps end in a stream sync, which cannot be captured)"); return -1; }
     if (on && !v->dv.ctr) {
         HIP_TRY(hipMalloc((void**)&v->dv.ctr, 3 * sizeof(uint32_t)), return -1);
@@ -1123,7 +1173,7 @@ bool image_fetch(DroneVec* v, int first, int count, StateImage& im) {
 
 int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "get_state")) return -1;
     if (!rows || first < 0 || count < 0 || first + count > v->n) { set_err("get_state: bad range"); return -1; }
     StateImage im;
     if (!image_fetch(v, first, count, im)) return -1;
@@ -1157,7 +1207,7 @@ int drone_vec_get_state(DroneVec* v, DroneStateRow* rows, int first, int count) 
 
 int drone_vec_set_state(DroneVec* v, const DroneStateRow* rows, int first, int count) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "set_state")) return -1;
     if (!rows || first < 0 || count < 0 || first + count > v->n) { set_err("set_state: bad range"); return -1; }
     if (count == 0) return 0;
     // the tiles at the edges of the range also hold neighbours: fetch, patch the rows, write the tiles back
@@ -1219,7 +1269,7 @@ int fetch_done_list(DroneVec* v, const uint32_t* cnt_dev, const uint32_t* ids_de
 
 int drone_vec_done_list(DroneVec* v, uint32_t* ids, int cap) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "done_list")) return -1;
     if (!v->dv.done_ids) { set_err("done list not enabled (compact_done=0)"); return -1; }
     if (!pull_counters(v)) return -1;
     if (!v->list_valid || v->step_launches == 0) return 0;  // after reset / after a fused rollout there is no list
@@ -1279,7 +1329,7 @@ int drone_gather_unique_id(unsigned char* id) {
 int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, int world, const int* counts, int root,
                                float* all_observations, float* all_rewards, unsigned char* all_terminals, unsigned char* all_truncations) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "gather_init")) return -1;
     if (v->gather) { set_err("gather already initialised on this handle"); return -1; }
     if (!id || world < 1 || rank < 0 || rank >= world) { set_err("gather_init: bad id / rank %d / world %d", rank, world); return -1; }
     if (root < -1 || root >= world) { set_err("gather_init: root %d outside [-1, %d)", root, world); return -1; }
@@ -1349,7 +1399,7 @@ int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int wo
 
 int drone_vec_gather(DroneVec* v) {
     Entry in(v);
-    if (!in) return -1;
+    if (!in || !idle(v, "gather")) return -1;
     Gather* g = v->gather;
     if (!g) { set_err("gather not initialised (drone_vec_gather_init)"); return -1; }
     Rccl* R = rccl();

@@ -73,6 +73,28 @@ class Drone:
                 infos.append(log)
         return self.observations, self.rewards, self.terminals, self.truncations, infos
 
+    def send(self, actions):
+        """Async half of ``step`` (PufferLib vec-envs' ``send`` / ``recv`` shape): hand over the actions and return while
+        the env steps; ``recv()`` then returns what ``step`` would have."""
+        if actions is not self.vec.actions:
+            if self.vec.torch_device is None:
+                self.vec.actions[:] = actions
+            else:
+                self.vec.actions.copy_(actions, non_blocking=True)
+        if self.vec.torch_device is not None:
+            self.vec.use_torch_stream()
+        self.vec.step_send()
+
+    def recv(self):
+        self.vec.step_recv()
+        self.tick += 1
+        infos = []
+        if self.log_interval and self.tick % self.log_interval == 0:
+            log = self.vec.log()
+            if log["n"] > 0:
+                infos.append(log)
+        return self.observations, self.rewards, self.terminals, self.truncations, infos
+
     def step_many(self, actions=None, k_steps=None):
         """K env steps in ONE launch with every step's outputs (``drone_vec_step_many``): open-loop action segments,
         action repeat, or — ``actions=None`` with ``k_steps`` — the device-side random policy. ``actions`` is a

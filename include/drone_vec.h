@@ -131,6 +131,15 @@ void drone_vec_reset(DroneVec* v, uint64_t seed);
  * rewards / terminals / truncations; finished envs auto-reset (SPEC.md §5). */
 void drone_vec_step(DroneVec* v);
 
+/* drone_vec_step in two halves, for a caller that has other work to do while the env steps (a vec-env's async
+ * send / recv; two handles stepping out of phase so that one's PCIe transfers overlap the other's kernel):
+ * step_send reads `actions` and enqueues the step and everything that can follow it on the stream; step_recv waits and
+ * delivers the outputs into the caller's buffers. send + recv = step, bit for bit. Between the two, the caller must
+ * not touch the five buffers, and every other call on the handle except drone_vec_sync / status / close fails with
+ * "not received". Device-buffer handles: send is the (asynchronous) step, recv returns at once. */
+void drone_vec_step_send(DroneVec* v);
+void drone_vec_step_recv(DroneVec* v);
+
 /* Fused rollout: `horizon` steps under the device-side random policy with
  * state held in registers; outputs written once at the horizon (SPEC.md §9).
  * `actions` is neither read nor written. */
