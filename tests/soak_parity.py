@@ -3,7 +3,7 @@
 
 Each case draws a task, a shard size (ragged sizes included), buffer kind, horizon, substeps, time step, scaled physics
 constants, env offset, the per-handle kernel variants (derived-target layout, packed RK4, graph-safe counters) and then a
-random SEQUENCE of path calls — step (random-policy, hostile or repeated actions, or the product's own fill_random_actions), rebinds of the action / output buffers, step_many (caller actions or the
+random SEQUENCE of path calls — step (random-policy, hostile or repeated actions, or the product's own fill_random_actions; as one call or as step_send + step_recv), rebinds of the action / output buffers, step_many (caller actions or the
 in-kernel policy), step_repeat, fused rollout, log, state read-back, a checkpoint round trip through get_state /
 set_state / set_gstep — mirrored call for call on the oracle. Every output of every call, every done-id list and the
 final state must match bit for bit.
@@ -141,18 +141,22 @@ def run_case(binding, oracle, case, rng, threads=8):
     compact = bool(case["over"]["compact_done"])
     history = []
     for i in range(case["ops"]):
-        op = str(rng.choice(["step", "step", "hostile", "repeat_last", "many", "many_policy", "step_repeat", "rollout", "log", "state", "checkpoint", "rebind", "fill"]))
+        op = str(rng.choice(["step", "step", "sendrecv", "hostile", "repeat_last", "many", "many_policy", "step_repeat", "rollout", "log", "state", "checkpoint", "rebind", "fill"]))
         history.append(op)
         what = f"{tag} after {history[:-1]} op {i} {op}"
-        if op in ("step", "hostile", "repeat_last"):
+        if op in ("step", "sendrecv", "hostile", "repeat_last"):
             for _ in range(int(rng.integers(1, 6))):
-                if op == "step":
+                if op in ("step", "sendrecv"):
                     o.fill_random_actions()
                 elif op == "hostile":
                     o.actions[:] = hostile_actions(rng, n)
                 put(v.actions, o.actions)
                 o.step()
-                v.step()
+                if op == "sendrecv":  # the step in two halves
+                    v.step_send()
+                    v.step_recv()
+                else:
+                    v.step()
                 sync(v)
                 assert_outputs_equal(o, v, what)
                 if compact:
