@@ -39,7 +39,24 @@ def main():
     ap.add_argument("--workers", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--threads", action="store_true", help="the workers are THREADS of one process (one handle and stream each) instead of processes")
     a = ap.parse_args()
+    if a.threads:
+        import queue
+        import threading
+
+        for w in a.workers:
+            barrier, out = threading.Barrier(w), queue.Queue()
+            ts = [threading.Thread(target=worker, args=(r, a.envs, a.steps, barrier, out)) for r in range(w)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join(300)
+            res = [out.get() for _ in ts]
+            slowest = max(r[1] for r in res)
+            print(f"{w} worker thread(s) of one process x {a.envs} envs, host buffers ({res[0][2]}): {slowest / a.steps * 1e6:.1f} us per step of every worker, "
+                  f"{w * a.envs * a.steps / slowest:.3e} env-steps/s in total", flush=True)
+        return
     ctx = mp.get_context("spawn")
     for w in a.workers:
         barrier, out = ctx.Barrier(w), ctx.Queue()
