@@ -257,7 +257,8 @@ bool host_to_device_actions(DroneVec* v) {
 // matters — or a fault, which only the runtime can report) falls back to hipStreamSynchronize. DRONE_HOST_SPIN=0 turns
 // the flag off. Measured with host/drone_host --fill 0 on one box: 15.4 -> 13.2 us per step at 256 envs, 16.7 -> 15.1 at
 // 1 024, 22.8 -> 19.6 at 4 096, 43.3 -> 41.1 at 16 384, no difference from 65 536 on (the step is PCIe-bound there).
-// puts the next sequence number on the stream, behind everything enqueued so far
+//
+// post_flag puts the next sequence number on the stream, behind everything enqueued so far; wait_zero_copy polls for it.
 void post_flag(DroneVec* v) {
     v->flag_posted = false;
     if (!v->h_flag) return;
