@@ -667,6 +667,16 @@ static PyObject* vec_device(PyObject* self, PyObject* args) {
     return PyLong_FromLong(drone_vec_device(h->v));
 }
 
+/* vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers */
+static PyObject* vec_host_transport(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    return PyLong_FromLong(drone_vec_host_transport(h->v));
+}
+
 static PyObject* vec_sync(PyObject* self, PyObject* args) {
     (void)self;
     PyObject* cap;
@@ -708,6 +718,7 @@ static PyMethodDef methods[] = {
     {"vec_fill_random_actions", vec_fill_random_actions, METH_VARARGS, "vec_fill_random_actions(handle, actions=None, gstep=None)"},
     {"vec_gstep", vec_gstep, METH_VARARGS, "vec_gstep(handle) -> int"},
     {"vec_device", vec_device, METH_VARARGS, "vec_device(handle) -> HIP device ordinal the env lives on"},
+    {"vec_host_transport", vec_host_transport, METH_VARARGS, "vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers"},
     {"vec_sync", vec_sync, METH_VARARGS, "vec_sync(handle): wait until everything enqueued on the env's stream has finished"},
     {"obs_dim", obs_dim, METH_VARARGS, "obs_dim(task) -> floats per observation row"},
     {NULL, NULL, 0, NULL}};

@@ -30,7 +30,8 @@ def host_buffers(n, task):
 
 
 def test_module_surface_and_argument_checks(ext):
-    for name in ("vec_init", "vec_reset", "vec_step", "vec_log", "vec_close", "vec_rollout", "vec_set_stream", "vec_fill_random_actions", "vec_gstep"):
+    for name in ("vec_init", "vec_reset", "vec_step", "vec_log", "vec_close", "vec_rollout", "vec_set_stream", "vec_fill_random_actions", "vec_gstep",
+                 "vec_send", "vec_recv", "vec_step_many", "vec_step_repeat", "vec_done_list_at", "vec_dlpack", "vec_device", "vec_sync", "vec_host_transport"):
         assert callable(getattr(ext, name))
     assert ext.obs_dim(0) == 20 and ext.obs_dim(3) == 24 and ext.TASK_SWARM == 2
     b = host_buffers(16, 0)
