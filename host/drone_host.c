@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
         crc = crc32_update(crc, obs, sizeof(float) * (size_t)envs * obs_dim); /* the reset observations */
         for (int t = 0; many > 0 && t < steps;) { /* the same CRC chain through K steps per call: step by step, obs / rew / term / trunc */
             const int k_now = steps - t < many ? steps - t : many;
-            for (int k = 0; k < k_now; k++) drone_vec_fill_random_actions(v, m_act + (size_t)k * envs * DRONE_ACT_DIM, drone_vec_gstep(v) + (uint32_t)k);
+            for (int k = 0; k < k_now; k++) drone_vec_fill_random_actions(v, m_act + (size_t)k * (size_t)envs * DRONE_ACT_DIM, drone_vec_gstep(v) + (uint32_t)k);
             drone_vec_step_many(v, k_now, m_act, m_obs, m_rew, m_term, m_trunc);
             for (int k = 0; k < k_now; k++) {
                 const size_t r0 = (size_t)k * (size_t)envs;
@@ -164,7 +164,7 @@ int main(int argc, char** argv) {
 
     /* (a') K env steps per call with every step's outputs (drone_vec_step_many): one launch and one round of copies per K steps */
     if (many > 0) {
-        for (int k = 0; k < many; k++) drone_vec_fill_random_actions(v, m_act + (size_t)k * envs * DRONE_ACT_DIM, drone_vec_gstep(v) + (uint32_t)k);
+        for (int k = 0; k < many; k++) drone_vec_fill_random_actions(v, m_act + (size_t)k * (size_t)envs * DRONE_ACT_DIM, drone_vec_gstep(v) + (uint32_t)k);
         drone_vec_step_many(v, many, m_act, m_obs, m_rew, m_term, m_trunc);
         const int calls = steps / many > 0 ? steps / many : 1;
         t0 = now_s();
