@@ -100,6 +100,8 @@ SYMBOLS = {
     "drone_vec_rollout": (None, [_P, C.c_int]),
     "drone_vec_step_many": (None, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "drone_vec_step_repeat": (None, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "drone_vec_host_pin": (C.c_int, [_P, _P, C.c_size_t, C.c_int]),
+    "drone_vec_host_unpin": (C.c_int, [_P, _P]),
     "drone_vec_log": (None, [_P, C.POINTER(DroneLog)]),
     "drone_vec_close": (None, [_P]),
     "drone_vec_set_stream": (C.c_int, [_P, _P]),

@@ -158,6 +158,7 @@ class DroneVec:
             self.terminals = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.truncations = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._seed = int(seed)
+        self._pinned_blocks = []
         self._h = self._f["drone_vec_init"](
             _ptr(self.observations), _ptr(self.actions), _ptr(self.rewards), _ptr(self.terminals), _ptr(self.truncations),
             n, seed, C.byref(self.cfg))
@@ -234,12 +235,19 @@ class DroneVec:
         self._f["drone_vec_rollout"](self._h, int(horizon))
         self._raise_if_failed()
 
-    def alloc_step_many(self, k_steps):
-        """Blocks of the handle's buffer kind for ``step_many`` (allocate once, reuse every call)."""
+    def alloc_step_many(self, k_steps, pinned=True):
+        """Blocks of the handle's buffer kind for ``step_many`` (allocate once, reuse every call). Host handles:
+        page-owning blocks, pinned (``drone_vec_host_pin``) unless ``pinned=False`` — the kernel then reads / writes
+        them in place over PCIe; unpinned ones go through device staging and copies."""
         n, od, K = self.num_envs, abi.obs_dim(self.cfg.task), int(k_steps)
         if self.torch_device is None:
-            return StepManyBuffers(K, np.zeros((K, n, abi.ACT_DIM), np.float32), np.zeros((K, n, od), np.float32), np.zeros((K, n), np.float32),
-                                   np.zeros((K, n), np.uint8), np.zeros((K, n), np.uint8))
+            blocks = (page_buffer((K, n, abi.ACT_DIM), np.float32), page_buffer((K, n, od), np.float32), page_buffer((K, n), np.float32),
+                      page_buffer((K, n), np.uint8), page_buffer((K, n), np.uint8))
+            if pinned:
+                for b in blocks:
+                    self._check(self._f["drone_vec_host_pin"](self._h, b.ctypes.data, b.nbytes, 1))
+                    self._pinned_blocks.append(b)  # unpinned at close, before the arrays can go away
+            return StepManyBuffers(K, *blocks)
         import torch
 
         dev = self.torch_device
@@ -288,6 +296,9 @@ class DroneVec:
 
     def close(self):
         if getattr(self, "_h", None):
+            for b in getattr(self, "_pinned_blocks", []):
+                self._f["drone_vec_host_unpin"](self._h, b.ctypes.data)
+            self._pinned_blocks = []
             self._f["drone_vec_close"](self._h)
             self._h = None
 

@@ -97,6 +97,7 @@ struct DroneVec {
     volatile uint32_t* h_flag;  // pinned + mapped
     void* d_flag;               // its device address
     uint32_t flag_seq;
+    bool flag_tried;            // ensure_flag ran (the flag is allocated on first need)
     bool flag_posted;           // the current flag_seq is already on the stream (drone_vec_step_send)
     bool pending;               // a step was sent and not yet received
     float* d_obs;        // host-buffer handles: device mirrors; device handles: the library-owned buffers, if any
@@ -258,7 +259,24 @@ bool host_to_device_actions(DroneVec* v) {
 // the flag off. Measured with host/drone_host --fill 0 on one box: 15.4 -> 13.2 us per step at 256 envs, 16.7 -> 15.1 at
 // 1 024, 22.8 -> 19.6 at 4 096, 43.3 -> 41.1 at 16 384, no difference from 65 536 on (the step is PCIe-bound there).
 //
+// ensure_flag allocates the flag (best effort: without it the waits are hipStreamSynchronize);
 // post_flag puts the next sequence number on the stream, behind everything enqueued so far; wait_zero_copy polls for it.
+void ensure_flag(DroneVec* v) {
+    if (v->h_flag || v->flag_tried) return;
+    v->flag_tried = true;
+    const char* sp = getenv("DRONE_HOST_SPIN");
+    if (sp && *sp && atoi(sp) == 0) return;
+    void* hf = nullptr;
+    if (hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&v->d_flag, hf, 0) == hipSuccess) {
+        v->h_flag = static_cast<volatile uint32_t*>(hf);
+        *v->h_flag = 0u;
+    } else {
+        (void)hipGetLastError();
+        if (hf) (void)hipHostFree(hf);
+        v->d_flag = nullptr;
+    }
+}
+
 void post_flag(DroneVec* v) {
     v->flag_posted = false;
     if (!v->h_flag) return;
@@ -595,6 +613,30 @@ int drone_vec_host_transport(const DroneVec* v) {
     return 1;
 }
 
+// Pin a host block the caller owns (on the handle's device), under the same page-ownership rule as the buffers given to init.
+int drone_vec_host_pin(DroneVec* v, void* p, size_t bytes, int pages_exclusive) {
+    Entry in(v);
+    if (!in) return -1;
+    if (!p || !bytes) { set_err("host_pin: NULL block or zero size"); return -1; }
+    if (already_pinned(p)) return 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0, whole = (bytes % kPage) == 0;
+    if (!aligned || !(whole || pages_exclusive)) {
+        set_err("host_pin: the block must start on a 4 KiB boundary and span whole pages (or be vouched for: pages_exclusive), see DroneConfig.host_pages_exclusive");
+        return -1;
+    }
+    HIP_TRY(host_register(p, (bytes + kPage - 1) / kPage * kPage, v, "drone_vec_host_pin"), return -1);
+    return 0;
+}
+
+int drone_vec_host_unpin(DroneVec* v, void* p) {
+    Entry in(v);
+    if (!in || !idle(v, "host_unpin")) return -1;
+    if (!p) { set_err("host_unpin: NULL block"); return -1; }
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);  // nothing of this handle may still be writing the block
+    HIP_TRY(hipHostUnregister(p), return -1);
+    return 0;
+}
+
 int drone_vec_buffers(const DroneVec* v, float** observations, float** actions, float** rewards, unsigned char** terminals, unsigned char** truncations) {
     if (!v) { set_err("NULL handle"); return -1; }
     if (observations) *observations = v->u_obs;
@@ -717,18 +759,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
                             !(reinterpret_cast<uintptr_t>(v->m_rew) & 3u);
             if (ok) {
                 v->zero_copy = true;
-                const char* sp = getenv("DRONE_HOST_SPIN");
-                if (!(sp && *sp && atoi(sp) == 0)) {  // best effort: without the flag the waits are hipStreamSynchronize
-                    void* hf = nullptr;
-                    if (hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&v->d_flag, hf, 0) == hipSuccess) {
-                        v->h_flag = static_cast<volatile uint32_t*>(hf);
-                        *v->h_flag = 0u;
-                    } else {
-                        (void)hipGetLastError();
-                        if (hf) (void)hipHostFree(hf);
-                        v->d_flag = nullptr;
-                    }
-                }
+                ensure_flag(v);
                 v->dv.obs = v->m_obs; v->dv.act = v->m_act; v->dv.rew = v->m_rew; v->dv.term = v->m_term; v->dv.trunc = v->m_trunc;
             } else {
                 drop_bounce(v);  // mirror transport after all
@@ -848,7 +879,7 @@ void drone_vec_rollout(DroneVec* v, int horizon) {
 namespace {
 
 // grow the K-dependent device storage of drone_vec_step_many (drained first: an earlier launch may still use the old blocks)
-bool many_reserve(DroneVec* v, int k_steps) {
+bool many_reserve(DroneVec* v, int k_steps, bool need_staging) {
     const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task), K = (size_t)k_steps;
     if (v->cfg.compact_done && k_steps > v->many_cap) {
         HIP_TRY(hipStreamSynchronize(v->stream), return false);
@@ -859,7 +890,7 @@ bool many_reserve(DroneVec* v, int k_steps) {
         HIP_TRY(hipMalloc((void**)&v->many_count, sizeof(uint32_t) * K), return false);
         v->many_cap = k_steps;
     }
-    if (v->host_buffers && k_steps > v->stage_cap) {
+    if (v->host_buffers && need_staging && k_steps > v->stage_cap) {
         HIP_TRY(hipStreamSynchronize(v->stream), return false);
         (void)hipFree(v->s_act); (void)hipFree(v->s_obs); (void)hipFree(v->s_rew); (void)hipFree(v->s_term); (void)hipFree(v->s_trunc);
         v->s_act = v->s_obs = v->s_rew = nullptr; v->s_term = v->s_trunc = nullptr;
@@ -902,17 +933,33 @@ void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat,
     if (k_steps < 1) { set_err("step_many: k_steps must be positive, got %d", k_steps); return; }
     if (!observations || !rewards || !terminals || !truncations) { set_err("step_many: NULL output block"); return; }
     const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task), K = (size_t)k_steps;
-    if (!many_reserve(v, k_steps)) return;
+    // Host handles: blocks the caller pinned beforehand (drone_host_pin, hipHostMalloc, hipHostRegister) are accessed by
+    // the kernel in place over PCIe — no staging, no copy commands; anything else goes through device staging and DMA.
     const float* d_act = actions;
     float* d_obs = observations;
     float* d_rew = rewards;
     unsigned char* d_term = terminals;
     unsigned char* d_trunc = truncations;
+    bool direct = false;
     if (v->host_buffers) {
+        const char* zc = getenv("DRONE_HOST_ZEROCOPY");
+        if (!(zc && *zc && atoi(zc) == 0) && (!actions || already_pinned(actions)) && already_pinned(observations) && already_pinned(rewards) &&
+            already_pinned(terminals) && already_pinned(truncations)) {
+            void* m[5] = {actions ? mapped_ptr(const_cast<float*>(actions)) : nullptr, mapped_ptr(observations), mapped_ptr(rewards), mapped_ptr(terminals), mapped_ptr(truncations)};
+            direct = (!actions || m[0]) && m[1] && m[2] && m[3] && m[4] && !(reinterpret_cast<uintptr_t>(m[0]) & 15u) && !(reinterpret_cast<uintptr_t>(m[1]) & 15u) &&
+                     !(reinterpret_cast<uintptr_t>(m[2]) & 3u);
+            if (direct) {
+                d_act = static_cast<const float*>(m[0]); d_obs = static_cast<float*>(m[1]); d_rew = static_cast<float*>(m[2]);
+                d_term = static_cast<unsigned char*>(m[3]); d_trunc = static_cast<unsigned char*>(m[4]);
+            }
+        }
+    }
+    if (!many_reserve(v, k_steps, !direct)) return;
+    if (v->host_buffers && !direct) {
         d_act = actions ? v->s_act : nullptr;
         d_obs = v->s_obs; d_rew = v->s_rew; d_term = v->s_term; d_trunc = v->s_trunc;
         if (actions) HIP_TRY(hipMemcpyAsync(v->s_act, actions, (repeat ? 1 : K) * n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return);
-    } else if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
+    } else if (!v->host_buffers && ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(actions) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u))) {
         set_err("step_many: device blocks must be 16-byte aligned (observations, actions) and 4-byte aligned (rewards)");
         return;
     }
@@ -922,7 +969,10 @@ void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat,
     v->gstep += (uint32_t)k_steps;
     v->list_valid = false;
     v->many_k = k_steps;
-    if (v->host_buffers) {
+    if (v->host_buffers && direct) {
+        ensure_flag(v);
+        (void)wait_zero_copy(v);
+    } else if (v->host_buffers) {
         HIP_TRY(hipMemcpyAsync(observations, v->s_obs, K * n * od * sizeof(float), hipMemcpyDeviceToHost, v->stream), return);
         HIP_TRY(hipMemcpyAsync(rewards, v->s_rew, K * n * sizeof(float), hipMemcpyDeviceToHost, v->stream), return);
         HIP_TRY(hipMemcpyAsync(terminals, v->s_term, K * n, hipMemcpyDeviceToHost, v->stream), return);

@@ -114,6 +114,14 @@ int main(int argc, char** argv) {
         m_term = (unsigned char*)page_alloc(kn);
         m_trunc = (unsigned char*)page_alloc(kn);
         if (!m_act || !m_obs || !m_rew || !m_term || !m_trunc) { fprintf(stderr, "out of memory\n"); return 1; }
+        /* page_alloc blocks own their pages: pinned, the kernel reads / writes them in place (DRONE_HOST_PIN_BLOCKS=0: staging + copies) */
+        const char* pb = getenv("DRONE_HOST_PIN_BLOCKS");
+        if (!(pb && pb[0] == '0') &&
+            (drone_vec_host_pin(v, m_act, sizeof(float) * kn * DRONE_ACT_DIM, 1) || drone_vec_host_pin(v, m_obs, sizeof(float) * kn * obs_dim, 1) ||
+             drone_vec_host_pin(v, m_rew, sizeof(float) * kn, 1) || drone_vec_host_pin(v, m_term, kn, 1) || drone_vec_host_pin(v, m_trunc, kn, 1))) {
+            fprintf(stderr, "drone_vec_host_pin failed: %s\n", drone_last_error());
+            return 1;
+        }
     }
 
     if (crc_mode) {
@@ -144,6 +152,7 @@ int main(int argc, char** argv) {
         DroneLog lg;
         drone_vec_log(v, &lg);
         printf("{\"mode\": \"crc\", \"task\": %d, \"envs\": %d, \"steps\": %d, \"steps_per_call\": %d, \"crc32\": %u, \"episodes\": %.0f}\n", task, envs, steps, many > 0 ? many : 1, crc, lg.n);
+        if (many > 0) { drone_vec_host_unpin(v, m_act); drone_vec_host_unpin(v, m_obs); drone_vec_host_unpin(v, m_rew); drone_vec_host_unpin(v, m_term); drone_vec_host_unpin(v, m_trunc); }
         drone_vec_close(v);
         if (!heap) { free(obs); free(act); free(rew); free(term); free(trunc); }
         return 0;
@@ -188,6 +197,7 @@ int main(int argc, char** argv) {
     printf("{\"log\": {\"n\": %.0f, \"episode_return\": %.5g, \"episode_length\": %.5g, \"score\": %.5g, \"oob\": %.5g}, \"sampled_dones\": %ld}\n",
            log.n, log.episode_return, log.episode_length, log.score, log.oob, dones);
     if (drone_vec_status(v)) { fprintf(stderr, "a call on the handle failed: %s\n", drone_vec_status_message(v)); return 1; }
+    if (many > 0) { drone_vec_host_unpin(v, m_act); drone_vec_host_unpin(v, m_obs); drone_vec_host_unpin(v, m_rew); drone_vec_host_unpin(v, m_term); drone_vec_host_unpin(v, m_trunc); }
     drone_vec_close(v);
     if (!heap) { free(obs); free(act); free(rew); free(term); free(trunc); }
     free(m_act); free(m_obs); free(m_rew); free(m_term); free(m_trunc);

@@ -23,6 +23,7 @@
 #ifndef DRONE_VEC_H
 #define DRONE_VEC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -165,6 +166,15 @@ void drone_vec_step_many(DroneVec* v, int k_steps, const float* actions, float* 
  * of drone_vec_step with an unchanged action buffer would do. Outputs as for drone_vec_step_many: every step's, K-major. */
 void drone_vec_step_repeat(DroneVec* v, int k_steps, const float* actions, float* observations, float* rewards,
                            unsigned char* terminals, unsigned char* truncations);
+
+/* Host handles: pin (and map) a host block the caller owns, on the handle's device, so that the kernel can access it in
+ * place — K-major blocks of drone_vec_step_many / drone_vec_step_repeat that are pinned (this call, hipHostMalloc,
+ * hipHostRegister) are read / written over PCIe directly, without device staging and copy commands (1 024 envs, K = 32:
+ * 5.4 -> ~2 us per env step). Same page-ownership rule as DroneConfig.host_pages_exclusive: the block must start on a
+ * 4 KiB boundary and either span whole pages or be vouched for (pages_exclusive = 1: its own mmap / posix_memalign block
+ * padded to whole pages). Unpin before freeing the block. 0 / -1 (drone_last_error). */
+int drone_vec_host_pin(DroneVec* v, void* block, size_t bytes, int pages_exclusive);
+int drone_vec_host_unpin(DroneVec* v, void* block);
 
 void drone_vec_log(DroneVec* v, DroneLog* out);
 void drone_vec_close(DroneVec* v);

@@ -165,7 +165,7 @@ def run_case(binding, oracle, case, rng, threads=8):
                 env_steps += n
         elif op in ("many", "many_policy", "step_repeat"):
             K = int(rng.integers(1, case.get("max_k", 9) + 1))
-            bufs = v.alloc_step_many(K)
+            bufs = v.alloc_step_many(K, pinned=bool(rng.integers(0, 2)))  # host handles: pinned blocks are accessed in place, others staged
             if op == "many":
                 acts = np.stack([hostile_actions(rng, n) if rng.random() < 0.3 else rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(K)])
                 put(bufs.actions, acts)

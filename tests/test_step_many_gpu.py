@@ -56,8 +56,8 @@ def test_step_many_equals_k_plain_steps(oracle, hip, task, device):
     n = 1000 if task != 2 else 1000 // 8 * 8  # ragged: 3 full workgroups + a partial one
     o, h = pair(oracle, hip, n, 17 + task, task, device=device, horizon=20)  # 49 steps: every env is truncated and reset twice
     ends = 0
-    for K in (1, 2, 7, 32, 7):
-        bufs = h.alloc_step_many(K)
+    for j, K in enumerate((1, 2, 7, 32, 7)):
+        bufs = h.alloc_step_many(K, pinned=bool(j % 2))  # host handles: staged blocks and pinned ones (accessed in place), alternating
         ends += check_call(o, h, bufs, K, f"task {task} K={K}")
         assert_state_equal(o.get_state(), h.get_state(), f"task {task} state after K={K}")
     assert ends >= 2 * n  # episode ends (and the resets inside the K steps) were exercised
@@ -196,3 +196,30 @@ def test_step_repeat_is_k_steps_under_one_action_block(oracle, hip, task, device
         assert_bits_equal(trunc, to_np(bufs.truncations), f"repeat {rep} truncations")
     assert_state_equal(o.get_state(), h.get_state(), "state after repeats")
     assert h.gstep == o.gstep == 48
+
+
+@pytest.mark.gpu
+def test_host_blocks_pinned_and_not(oracle, hip):
+    """drone_vec_host_pin: pinned K-major host blocks are read / written by the kernel in place, unpinned ones go through
+    staging; same results; the page rule is enforced; plain heap blocks still work (staged)."""
+    import ctypes as C
+
+    n, K, seed = 2048, 6, 8
+    o, h = pair(oracle, hip, n, seed, 1, device=None, horizon=15, compact_done=1)
+    for pinned in (True, False, True):
+        bufs = h.alloc_step_many(K, pinned=pinned)
+        check_call(o, h, bufs, K, f"pinned={pinned}", lists=True)
+    heap = hip.StepManyBuffers(K, np.zeros((K, n, 4), np.float32), np.zeros((K, n, 20), np.float32), np.zeros((K, n), np.float32),
+                               np.zeros((K, n), np.uint8), np.zeros((K, n), np.uint8))
+    check_call(o, h, heap, K, "heap blocks", lists=True)
+    # the rule: an unaligned block is refused, not registered
+    odd = np.zeros(8192 + 64, np.uint8)[64:]
+    assert h._f["drone_vec_host_pin"](h._h, odd.ctypes.data, odd.nbytes, 0) == -1
+    assert b"4 KiB" in h._f["drone_last_error"]()
+    h.clear_status()
+    ok = hip.page_buffer((4096,), np.uint8)
+    assert h._f["drone_vec_host_pin"](h._h, ok.ctypes.data, ok.nbytes, 0) == 0
+    assert h._f["drone_vec_host_pin"](h._h, ok.ctypes.data, ok.nbytes, 0) == 0  # already pinned: fine
+    assert h._f["drone_vec_host_unpin"](h._h, ok.ctypes.data) == 0
+    assert_state_equal(o.get_state(), h.get_state(), "state")
+    h.close()
