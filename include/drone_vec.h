@@ -152,7 +152,8 @@ void drone_vec_rollout(DroneVec* v, int horizon);
  *   actions      [K][N][4] f32, or NULL: the SPEC.md §2 random policy is drawn in the kernel (as drone_vec_rollout does)
  *   observations [K][N][drone_obs_dim(task)] f32, rewards [K][N] f32, terminals / truncations [K][N] u8
  * all of the handle's buffer kind (device kind: 16-byte aligned observations / actions, written asynchronously on the
- * stream; host kind: copied through device staging, returns after the copy). The handle's bound per-step buffers are
+ * stream; host kind: blocks pinned beforehand — drone_vec_host_pin — are read / written by the kernel in place, others are
+ * copied through device staging; returns when the outputs are in the caller's memory). The handle's bound per-step buffers are
  * neither read nor written. State stays in registers between the K steps: the dependent-launch boundary and the state
  * planes' HBM traffic are paid once per K steps (hover: 102 + 176 / K bytes per env-step instead of 278), which is what
  * small shards (one wave per SIMD, launch-boundary bound) need. Consumers: open-loop action segments, action repeat /
