@@ -667,6 +667,25 @@ static PyObject* vec_device(PyObject* self, PyObject* args) {
     return PyLong_FromLong(drone_vec_device(h->v));
 }
 
+/* vec_host_pin(handle, buffer, pages_exclusive=0) / vec_host_unpin(handle, buffer): pin a page-owning host block (any object
+ * with a writable C-contiguous buffer, e.g. a numpy array over its own mmap) so that vec_step_many / vec_step_repeat access
+ * it in place. The caller keeps the object alive and unpins it before letting it go. */
+static PyObject* host_pin_impl(PyObject* args, int pin) {
+    PyObject *cap, *buf;
+    int excl = 0;
+    if (!PyArg_ParseTuple(args, pin ? "OO|i" : "OO", &cap, &buf, &excl)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    Py_buffer view;
+    if (PyObject_GetBuffer(buf, &view, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) return NULL;
+    const int rc = pin ? drone_vec_host_pin(h->v, view.buf, (size_t)view.len, excl) : drone_vec_host_unpin(h->v, view.buf);
+    PyBuffer_Release(&view);
+    if (rc != 0) { PyErr_Format(PyExc_RuntimeError, "libdrone_hip: %s", drone_last_error()); drone_vec_clear_status(h->v); return NULL; }
+    Py_RETURN_NONE;
+}
+static PyObject* vec_host_pin(PyObject* self, PyObject* args) { (void)self; return host_pin_impl(args, 1); }
+static PyObject* vec_host_unpin(PyObject* self, PyObject* args) { (void)self; return host_pin_impl(args, 0); }
+
 /* vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers */
 static PyObject* vec_host_transport(PyObject* self, PyObject* args) {
     (void)self;
@@ -718,6 +737,8 @@ static PyMethodDef methods[] = {
     {"vec_fill_random_actions", vec_fill_random_actions, METH_VARARGS, "vec_fill_random_actions(handle, actions=None, gstep=None)"},
     {"vec_gstep", vec_gstep, METH_VARARGS, "vec_gstep(handle) -> int"},
     {"vec_device", vec_device, METH_VARARGS, "vec_device(handle) -> HIP device ordinal the env lives on"},
+    {"vec_host_pin", vec_host_pin, METH_VARARGS, "vec_host_pin(handle, buffer, pages_exclusive=0): pin a page-owning host block for in-place access by vec_step_many"},
+    {"vec_host_unpin", vec_host_unpin, METH_VARARGS, "vec_host_unpin(handle, buffer)"},
     {"vec_host_transport", vec_host_transport, METH_VARARGS, "vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers"},
     {"vec_sync", vec_sync, METH_VARARGS, "vec_sync(handle): wait until everything enqueued on the env's stream has finished"},
     {"obs_dim", obs_dim, METH_VARARGS, "obs_dim(task) -> floats per observation row"},

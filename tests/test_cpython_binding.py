@@ -31,7 +31,7 @@ def host_buffers(n, task):
 
 def test_module_surface_and_argument_checks(ext):
     for name in ("vec_init", "vec_reset", "vec_step", "vec_log", "vec_close", "vec_rollout", "vec_set_stream", "vec_fill_random_actions", "vec_gstep",
-                 "vec_send", "vec_recv", "vec_step_many", "vec_step_repeat", "vec_done_list_at", "vec_dlpack", "vec_device", "vec_sync", "vec_host_transport"):
+                 "vec_send", "vec_recv", "vec_step_many", "vec_step_repeat", "vec_done_list_at", "vec_dlpack", "vec_device", "vec_sync", "vec_host_transport", "vec_host_pin", "vec_host_unpin"):
         assert callable(getattr(ext, name))
     assert ext.obs_dim(0) == 20 and ext.obs_dim(3) == 24 and ext.TASK_SWARM == 2
     b = host_buffers(16, 0)
@@ -242,3 +242,39 @@ def test_dlpack_argument_checks_need_no_gpu(ext):
     # a refused producer keeps its memory: the capsule was not consumed
     assert float(cpu[0].sum()) == 0.0 and cpu[0].data_ptr() != 0
     assert callable(ext.vec_dlpack)
+
+
+@pytest.mark.gpu
+def test_binding_pinned_step_many_blocks(ext, oracle):
+    """vec_host_pin: page-owning numpy blocks pinned once, then written by vec_step_many in place."""
+    import mmap
+
+    n, K, seed = 1024, 5, 2
+
+    def page_array(shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        m = mmap.mmap(-1, (nbytes + 4095) // 4096 * 4096)
+        return np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    obs, act, rew, term, trunc = host_buffers(n, 0)
+    h = ext.vec_init(obs, act, rew, term, trunc, n, seed)
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(0), threads=4)
+    ext.vec_reset(h, seed)
+    o.reset(seed)
+    blocks = [page_array((K, n, 4), np.float32), page_array((K, n, 20), np.float32), page_array((K, n), np.float32), page_array((K, n), np.uint8), page_array((K, n), np.uint8)]
+    for b in blocks:
+        ext.vec_host_pin(h, b, 1)
+    with pytest.raises(RuntimeError, match="4 KiB"):
+        ext.vec_host_pin(h, np.zeros(5000, np.uint8)[8:], 0)
+    assert ext.vec_gstep(h) == 0  # the refused pin did not poison the handle
+    for rep in range(3):
+        acts = np.random.default_rng(rep).uniform(-1, 1, (K, n, 4)).astype(np.float32)
+        blocks[0][...] = acts
+        want = o.step_many(K, acts)
+        ext.vec_step_many(h, K, *blocks)
+        assert_bits_equal(want[0], blocks[1], f"obs {rep}")
+        assert_bits_equal(want[1], blocks[2], f"rew {rep}")
+        assert_bits_equal(want[2], blocks[3], f"term {rep}")
+    for b in blocks:
+        ext.vec_host_unpin(h, b)
+    ext.vec_close(h)
