@@ -105,14 +105,17 @@ def test_self_launch_returns_the_childrens_failure_without_a_gpu():
 @pytest.mark.gpu
 def test_two_rank_launch_reports_the_metrics_configuration(hip):
     """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on a 1-GPU box: the oversubscribed gloo smoke path.
-    2^20-style strong split (here 2^17 total to keep it short), the named records, `value` = configs[2]."""
+    2^20-style strong split (here 2^17 total to keep it short), the named records, `value` = the sharded path itself,
+    configs[2]'s per-step exchange beside it."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--total-envs", "131073"],
                        capture_output=True, text=True, timeout=900, env=env)
     d = check_two_rank_line(r)
-    assert d["value_from"] == "gather_step" and d["value"] == d["records"]["gather_step"]["env_steps_per_s"]
-    assert d["ms_per_step"] == d["records"]["gather_step"]["ms_per_step"]
+    assert d["value_from"] == "no_gather" and d["value"] == d["records"]["no_gather"]["env_steps_per_s"]
+    assert d["ms_per_step"] == d["records"]["no_gather"]["ms_per_step"]
+    assert d["host_boundary_gather"]["gather_step"]["env_steps_per_s"] == d["records"]["gather_step"]["env_steps_per_s"]
+    assert "rollout_gather" in d["host_boundary_gather"]
     assert d["config"]["envs_per_gpu"] == 65537  # ragged split of 131073: rank 0 takes the extra env (shard_range)
     for name, rec in d["records"].items():
         if name != "c_host_mp":
