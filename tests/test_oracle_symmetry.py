@@ -131,3 +131,20 @@ def test_rotation_of_the_world_about_the_vertical(oracle, angle):
         assert np.array_equal(got[k]["rpm"], base[k]["rpm"]), f"rpm after {k + 1} steps"
         same_attitude(got[k]["quat"], qmul(qz, base[k]["quat"]), f"attitude after {k + 1} steps", tol)
         close(got[k]["ep_return"], base[k]["ep_return"], f"return after {k + 1} steps", 1e-4)
+
+
+def test_translation_of_drone_and_target(oracle):
+    """Moving the drone and its target by the same vector changes nothing the dynamics can see: velocities, attitudes,
+    rates and rotor speeds stay bit for bit, positions move by the vector (to the rounding of a larger coordinate)."""
+    rows, acts = start(oracle)
+    base = run(oracle, rows, acts)
+    d = np.array([2.0, -4.0, 1.0], np.float32)
+    t = rows.copy()
+    t["pos"] = rows["pos"] + d
+    t["target"] = rows["target"] + d
+    got = run(oracle, t, acts)
+    for k in (0, 9, STEPS - 1):
+        for f in ("vel", "quat", "omega", "rpm"):
+            assert np.array_equal(got[k][f], base[k][f]), f"{f} after {k + 1} steps"
+        close(got[k]["pos"], base[k]["pos"] + d, f"pos after {k + 1} steps", 2e-6)
+        close(got[k]["ep_return"], base[k]["ep_return"], f"return after {k + 1} steps", 1e-4)
