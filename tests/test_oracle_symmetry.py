@@ -148,3 +148,38 @@ def test_translation_of_drone_and_target(oracle):
             assert np.array_equal(got[k][f], base[k][f]), f"{f} after {k + 1} steps"
         close(got[k]["pos"], base[k]["pos"] + d, f"pos after {k + 1} steps", 2e-6)
         close(got[k]["ep_return"], base[k]["ep_return"], f"return after {k + 1} steps", 1e-4)
+
+
+def test_doubling_every_inertial_and_aerodynamic_constant(oracle):
+    """Dimensional analysis: mass, the three inertias, thrust, rotor-torque, drag and angular-damping coefficients all
+    times s leave every acceleration unchanged. With s = 2 every product in the step scales exactly, so the trajectory
+    must come out bit for bit (a constant applied on one side of an equation only would break it)."""
+    rows, acts = start(oracle)
+
+    def fly(scale):
+        cfg = oracle.default_config(0, **OVER)
+        for f in ("mass", "ixx", "iyy", "izz", "k_thrust", "k_torque", "k_drag", "k_ang_damp"):
+            setattr(cfg, f, getattr(cfg, f) * scale)
+        v = oracle.OracleVec(N, seed=SEED, cfg=cfg, threads=2)
+        v.reset(SEED)
+        v.set_state(rows)
+        for a in acts:
+            v.actions[:] = a
+            v.step()
+        return v.get_state(), v.rewards.copy()
+
+    (a, ra), (b, rb), (c, rc) = fly(1.0), fly(2.0), fly(0.5)
+    for f in ("pos", "vel", "quat", "omega", "rpm", "ep_return"):
+        assert np.array_equal(a[f], b[f]), f"{f}: constants x 2"
+        assert np.array_equal(a[f], c[f]), f"{f}: constants x 0.5"
+    assert np.array_equal(ra, rb) and np.array_equal(ra, rc)
+    # the control: scaling the mass alone does change the flight
+    cfg = oracle.default_config(0, **OVER)
+    cfg.mass *= 2.0
+    v = oracle.OracleVec(N, seed=SEED, cfg=cfg, threads=2)
+    v.reset(SEED)
+    v.set_state(rows)
+    for x in acts:
+        v.actions[:] = x
+        v.step()
+    assert np.max(np.abs(v.get_state()["pos"] - a["pos"])) > 1e-2
