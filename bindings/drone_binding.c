@@ -117,7 +117,7 @@ static const Field kFields[] = {
     F_(bound, 'f'), F_(spawn_extent, 'f'), F_(target_extent, 'f'), F_(tilt_init, 'f'),
     F_(hover_radius, 'f'), F_(waypoint_radius, 'f'), F_(wind_theta, 'f'), F_(wind_sigma, 'f'), F_(wind_max, 'f'),
     F_(c_omega, 'f'), F_(c_action, 'f'), F_(crash_penalty, 'f'), F_(progress_scale, 'f'), F_(waypoint_bonus, 'f'),
-    F_(collision_radius, 'f'), F_(proximity_radius, 'f'), F_(c_proximity, 'f'), F_(gate_radius, 'f'), F_(host_pages_exclusive, 'i'),
+    F_(collision_radius, 'f'), F_(proximity_radius, 'f'), F_(c_proximity, 'f'), F_(gate_radius, 'f'), F_(host_pages_exclusive, 'i'), F_(state_layout, 'i'),
 };
 #undef F_
 

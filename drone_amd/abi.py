@@ -22,6 +22,9 @@ def obs_dim(task):
 
 BUFFERS_HOST = 0
 BUFFERS_DEVICE = 1
+LAYOUT_AUTO = 0            # DroneConfig.state_layout: by footprint (hover / swarm from ~2^19 envs on drop the target plane)
+LAYOUT_TARGET_PLANE = 1
+LAYOUT_DERIVED_TARGET = 2
 
 _F = C.c_float
 
@@ -48,6 +51,7 @@ class DroneConfig(C.Structure):
         ("collision_radius", _F), ("proximity_radius", _F), ("c_proximity", _F),
         ("gate_radius", _F),
         ("host_pages_exclusive", C.c_int32),
+        ("state_layout", C.c_int32),
     ]
 
     def as_dict(self):
@@ -90,6 +94,7 @@ SYMBOLS = {
     "drone_config_default": (None, [C.POINTER(DroneConfig), C.c_int]),
     "drone_obs_dim": (C.c_int, [C.c_int]),
     "drone_vec_host_transport": (C.c_int, [_P]),
+    "drone_vec_variant": (C.c_char_p, [_P]),
     "drone_vec_bytes_per_env_step": (C.c_int, [_P]),
     "drone_device_count": (C.c_int, []),
     "drone_vec_init": (_P, [_P, _P, _P, _P, _P, C.c_int, C.c_uint64, C.POINTER(DroneConfig)]),

@@ -119,7 +119,9 @@ class DroneVec:
         self._f = _fns if fns is None else fns
         self.num_envs = int(num_envs)
         n = self.num_envs
-        self.cfg = cfg if cfg is not None else default_config(task, **overrides)
+        # a private copy: the handle adjusts buffer_kind / device / host_pages_exclusive below, and a caller's cfg object
+        # reused for a second handle must not inherit them (page ownership vouched for by accident)
+        self.cfg = abi.DroneConfig.from_buffer_copy(cfg) if cfg is not None else default_config(task, **overrides)
         self._h = None
         if buffers is not None:
             # caller-owned buffers (the PufferLib contract: the vec-env allocates them, possibly as
@@ -246,7 +248,7 @@ class DroneVec:
             if pinned:
                 for b in blocks:
                     self._check(self._f["drone_vec_host_pin"](self._h, b.ctypes.data, b.nbytes, 1))
-                    self._pinned_blocks.append(b)  # unpinned at close, before the arrays can go away
+                    self._pinned_blocks.append(b)  # unpinned by free_step_many or at close, before the arrays can go away
             return StepManyBuffers(K, *blocks)
         import torch
 
@@ -254,6 +256,19 @@ class DroneVec:
         return StepManyBuffers(K, torch.zeros((K, n, abi.ACT_DIM), dtype=torch.float32, device=dev), torch.zeros((K, n, od), dtype=torch.float32, device=dev),
                                torch.zeros((K, n), dtype=torch.float32, device=dev), torch.zeros((K, n), dtype=torch.uint8, device=dev),
                                torch.zeros((K, n), dtype=torch.uint8, device=dev))
+
+    def free_step_many(self, bufs):
+        """Unpin and forget the host blocks of an ``alloc_step_many`` result (a caller that changes K allocates new
+        blocks; without this the old pinned K x N blocks stay registered and referenced until ``close``). Device blocks
+        are plain tensors: nothing to do."""
+        if self.torch_device is not None or not getattr(self, "_h", None):
+            return
+        for b in (bufs.actions, bufs.observations, bufs.rewards, bufs.terminals, bufs.truncations):
+            for k, held in enumerate(self._pinned_blocks):
+                if held is b:
+                    self._check(self._f["drone_vec_host_unpin"](self._h, b.ctypes.data))
+                    del self._pinned_blocks[k]
+                    break
 
     def step_many(self, bufs, policy=False):
         """K env steps in one launch with every step's outputs (``drone_vec_step_many``): reads ``bufs.actions`` (or,
@@ -317,6 +332,15 @@ class DroneVec:
     def bytes_per_env_step(self):
         """Algorithmic HBM bytes per env-step of the per-step kernel for this handle (task + state layout)."""
         return self._f["drone_vec_bytes_per_env_step"](self._h)
+
+    @property
+    def variant(self):
+        """Which per-step kernel instantiation and launch choices this handle uses (``drone_vec_variant``), as text and
+        parsed: {'task': 0, 'compact': 0, 'stream': 0, 'dt': 1, 'order': 1, 'line_complete': 0, 'packed_rk4': 0, 'bytes': 262}."""
+        import re
+
+        text = self._f["drone_vec_variant"](self._h).decode()
+        return text, {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)", text)}
 
     @property
     def host_transport(self):
@@ -385,7 +409,8 @@ class DroneVec:
         self._check(self._f["drone_vec_set_state"](self._h, rows.ctypes.data, first, len(rows)))
 
     # -- checkpoint / resume: everything a run needs to continue bit for bit --
-    _CKPT_CFG_SKIP = ("struct_size", "buffer_kind", "device", "host_pages_exclusive")  # where the buffers live is the resuming process's business
+    # where the buffers live, and how the device lays the state out, are the resuming process's business (rows are layout-free)
+    _CKPT_CFG_SKIP = ("struct_size", "buffer_kind", "device", "host_pages_exclusive", "state_layout")
 
     def save_checkpoint(self, path):
         """Write the shard's state rows, the vec-level step counter, the seed the RNG streams are keyed on, the env

@@ -368,12 +368,17 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
         L.tgt[i] = P.target_extent * s16(half16(u, 3u + i));
         t[i] = P.tilt_init * s16(half16(u, 6u + i));
     }
+    // SPEC v5: (1, t) scaled to unit length by two Newton steps of 1/sqrt(n2) about 1 — 5 operations where the correctly
+    // rounded sqrt + divide took 28 (two quarter-rate transcendentals among them) on the episode-end path
     const float n2 = fma_(t[0], t[0], fma_(t[1], t[1], fma_(t[2], t[2], 1.0f)));
-    const float inv = 1.0f / sqrtf(n2);
-    L.s.q[0] = inv;
-    L.s.q[1] = t[0] * inv;
-    L.s.q[2] = t[1] * inv;
-    L.s.q[3] = t[2] * inv;
+    const float s1 = fma_(-0.5f, n2, 1.5f);
+    const float m = (n2 * s1) * s1;
+    const float s2 = fma_(-0.5f, m, 1.5f);
+    const float sc = s1 * s2;
+    L.s.q[0] = sc;
+    L.s.q[1] = t[0] * sc;
+    L.s.q[2] = t[1] * sc;
+    L.s.q[3] = t[2] * sc;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         L.s.v[i] = 0.0f;
@@ -537,14 +542,10 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
     out.trunc = trunc;
     out.perf = out.score = out.ep_return = out.ep_len = 0.0f;
     if (oob || trunc) {
-        float score, perf;
-        if (TASK != DRONE_TASK_WAYPOINT && TASK != DRONE_TASK_RACE) {
-            score = (float)L.score_count / (float)L.tick;
-            perf = score;
-        } else {
-            score = (float)L.score_count;
-            perf = L.score_count >= 8u ? 1.0f : (float)L.score_count * 0.125f;
-        }
+        // SPEC v5: hover / swarm log the COUNT of steps within hover_radius (vec_log divides by the steps flown): no division here
+        const float score = (float)L.score_count;
+        float perf = score;
+        if (TASK == DRONE_TASK_WAYPOINT || TASK == DRONE_TASK_RACE) perf = L.score_count >= 8u ? 1.0f : score * 0.125f;
         out.perf = perf;
         out.score = score;
         out.ep_return = L.ep_return;

@@ -130,10 +130,16 @@ struct DroneVec {
     int many_k;          // k_steps of the last drone_vec_step_many, 0 if the last path call was something else
     float* s_act; float* s_obs; float* s_rew; unsigned char* s_term; unsigned char* s_trunc;
     int stage_cap;       // steps the staging blocks hold
+    // blocks drone_vec_host_pin registered on this handle (and only those: host_unpin drops nothing else)
+    void* pinned_blocks[64];
+    int n_pinned_blocks;
+    char variant[192];   // drone_vec_variant
     // sticky status: the first failure of any call on this handle (drone_vec_status)
     int status;
     char status_msg[512];
-    struct Gather* gather;  // host-boundary all-gather over RCCL (drone_vec_gather_init), or null
+    struct Gather* gather;  // host-boundary exchange (RCCL: drone_vec_gather_init[_root]; peer stores: drone_vec_gather_init_peer), or null
+    // peer-store exchange: the global buffers this (root) handle exported with drone_vec_gather_peer_export
+    float* px_obs; float* px_rew; unsigned char* px_term; unsigned char* px_trunc;
 };
 
 namespace {
@@ -230,6 +236,11 @@ bool validate(const DroneConfig* c, int num_envs) {
                     num_envs, (unsigned long long)(0xFFFFFFFFull / 7u - kBlock));
             return false;
         }
+    }
+    if (c->state_layout != DRONE_LAYOUT_AUTO && c->state_layout != DRONE_LAYOUT_TARGET_PLANE && c->state_layout != DRONE_LAYOUT_DERIVED_TARGET) { set_err("unknown state_layout %d", c->state_layout); return false; }
+    if (c->state_layout == DRONE_LAYOUT_DERIVED_TARGET && !(task_has_derived_target(c->task) && c->horizon <= 65535)) {
+        set_err("state_layout = DRONE_LAYOUT_DERIVED_TARGET needs the hover or swarm task and horizon <= 65535 (task %d, horizon %d)", c->task, c->horizon);
+        return false;
     }
     if (c->buffer_kind != DRONE_BUFFERS_HOST && c->buffer_kind != DRONE_BUFFERS_DEVICE) { set_err("unknown buffer_kind %d", c->buffer_kind); return false; }
     if (c->substeps < 1 || c->horizon < 1) { set_err("substeps and horizon must be >= 1"); return false; }
@@ -403,17 +414,29 @@ void leave_zero_copy(DroneVec* v) {
 // hipHostRegister) is used as it is. Everything else is left alone and goes through plain pageable copies.
 constexpr uintptr_t kPage = 4096;
 
-bool already_pinned(const void* p) {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return at.type == hipMemoryTypeHost;
+// Pinned by its owner (hipHostMalloc / hipHostRegister) over ALL of [p, p + bytes): the first and the last byte are both
+// pinned host memory and map to device addresses exactly bytes - 1 apart, i.e. one mapping covers the block. (ADVICE r3:
+// looking at the first byte only accepted a slice that starts inside someone's registration and ends outside it; the
+// kernel then faulted on the tail instead of the call falling back to staging.)
+bool already_pinned(const void* p, size_t bytes) {
+    if (!p || !bytes) return false;
+    hipPointerAttribute_t a0, a1;
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a0.type != hipMemoryTypeHost) return false;
+    if (bytes == 1) return true;
+    const char* last = static_cast<const char*>(p) + (bytes - 1);
+    if (hipPointerGetAttributes(&a1, last) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a1.type != hipMemoryTypeHost) return false;
+    if (a0.devicePointer && a1.devicePointer)
+        return static_cast<const char*>(a1.devicePointer) - static_cast<const char*>(a0.devicePointer) == (ptrdiff_t)(bytes - 1);
+    return true;
 }
 
 // returns true if the buffer ends up pinned (by us: v->registered[slot]; or by its owner)
 bool pin_caller_buffer(DroneVec* v, int slot, void* p, size_t bytes) {
     v->registered[slot] = false;
     v->registered_ptr[slot] = p;
-    if (already_pinned(p)) return true;
+    if (already_pinned(p, bytes)) return true;
     const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0;
     const bool whole = (bytes % kPage) == 0;
     if (!aligned || !(whole || v->cfg.host_pages_exclusive)) return false;
@@ -512,6 +535,19 @@ struct Gather {
     unsigned char* h_term = nullptr;
     unsigned char* h_trunc = nullptr;
     bool h_registered[4] = {false, false, false, false};  // the global host buffers pinned by gather_init
+    // ---- peer-store exchange (round 4; drone_vec_gather_init_peer): no collective. The root exported its global
+    // buffers as IPC handles; every other rank mapped them and bound its OUTPUT pointers to its rows in them, so its step
+    // kernel's stores land in the root's HBM over xGMI. What is left of the "gather" is a handshake through a page of
+    // flags in host memory shared by the ranks: post[r] = launches rank r has published, ack = rounds the root has consumed.
+    bool peer = false;
+    void* peer_base[4] = {nullptr, nullptr, nullptr, nullptr};  // IPC mappings opened here (non-root ranks)
+    volatile uint32_t* flags = nullptr;  // the shared page: post[world] then ack
+    char* d_flags = nullptr;             // its device address (hipStreamWriteValue32 / hipStreamWaitValue32)
+    bool flags_registered = false;
+    bool gpu_waits = true;               // false once hipStreamWaitValue32 refused the flag memory: the host polls instead
+    uint32_t seq = 0;                    // rounds this rank has published (non-root) / collected (root)
+    uint32_t acked = 0;                  // root: last round whose consumption it has announced
+    float* own_obs = nullptr; float* own_rew = nullptr; unsigned char* own_term = nullptr; unsigned char* own_trunc = nullptr;  // the handle's output bindings before the exchange took them over
 };
 
 namespace {
@@ -522,6 +558,13 @@ void gather_destroy(DroneVec* v) {
     if (g->comm) {
         Rccl* R = rccl();
         if (R) (void)R->CommDestroy(g->comm);
+    }
+    if (g->peer) {  // give the handle its own output buffers back, then drop the mappings
+        if (v->stream) (void)hipStreamSynchronize(v->stream);
+        v->dv.obs = g->own_obs; v->dv.rew = g->own_rew; v->dv.term = g->own_term; v->dv.trunc = g->own_trunc;
+        for (int k = 0; k < 4; k++)
+            if (g->peer_base[k]) (void)hipIpcCloseMemHandle(g->peer_base[k]);
+        if (g->flags_registered) host_unregister(const_cast<uint32_t*>(g->flags), v, "peer-store flag page");
     }
     void* hosts[4] = {g->h_obs, g->h_rew, g->h_term, g->h_trunc};
     for (int k = 0; k < 4; k++)
@@ -534,6 +577,64 @@ void gather_destroy(DroneVec* v) {
     }
     delete g;
     v->gather = nullptr;
+}
+
+// ---- peer-store exchange: the handshake ----
+// One value of the shared flag page reaches `want` (the counters only grow; compared as signed differences so that a
+// wrap after 2^32 rounds is harmless on the host path). On the stream where the hardware can wait for it
+// (hipStreamWaitValue32: the command processor polls the word, no host involvement); where it cannot, the host drains
+// the stream and polls, bounded by DRONE_PEER_TIMEOUT_MS (default 10 s) so that a dead peer is an error, not a hang.
+bool peer_wait_ge(DroneVec* v, Gather* g, int slot, uint32_t want) {
+    if (g->gpu_waits) {
+        const hipError_t e = hipStreamWaitValue32(v->stream, g->d_flags + 4 * slot, want, hipStreamWaitValueGte, 0xFFFFFFFFu);
+        if (e == hipSuccess) return true;
+        (void)hipGetLastError();
+        g->gpu_waits = false;
+    }
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);
+    const char* t = getenv("DRONE_PEER_TIMEOUT_MS");
+    const long limit_ms = (t && *t) ? atol(t) : 10000;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t spins = 0;; spins++) {
+        if ((int32_t)(__atomic_load_n(g->flags + slot, __ATOMIC_ACQUIRE) - want) >= 0) return true;
+        if ((spins & 1023u) == 1023u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000L + (t1.tv_nsec - t0.tv_nsec) / 1000000L > limit_ms) {
+                set_err("peer-store exchange: flag %d did not reach %u within %ld ms (a rank died or did not call drone_vec_gather)", slot, want, limit_ms);
+                return false;
+            }
+        }
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+// publish `value` in flag `slot` behind everything enqueued on the stream so far
+bool peer_post(DroneVec* v, Gather* g, int slot, uint32_t value) {
+    if (hipStreamWriteValue32(v->stream, g->d_flags + 4 * slot, value, 0) == hipSuccess) return true;
+    (void)hipGetLastError();
+    HIP_TRY(hipStreamSynchronize(v->stream), return false);
+    __atomic_store_n(g->flags + slot, value, __ATOMIC_RELEASE);
+    return true;
+}
+
+// Before any launch that writes the output buffers (reset, step, rollout): the back-pressure half of the handshake.
+// A non-root rank's kernel is about to overwrite its rows of the root's buffers with round seq + 1: it may, once the
+// root has said that round seq has been consumed. The root says so here, at the start of ITS next launch — the
+// consumer's reads were enqueued on the same stream between drone_vec_gather and this call, so they are ordered ahead.
+bool peer_before_launch(DroneVec* v) {
+    Gather* g = v->gather;
+    if (!g || !g->peer || g->seq == 0) return true;
+    if (g->rank == g->root) {
+        if (g->acked != g->seq) {
+            if (!peer_post(v, g, g->world, g->seq)) return false;
+            g->acked = g->seq;
+        }
+        return true;
+    }
+    return peer_wait_ge(v, g, g->world, g->seq);
 }
 
 }  // namespace
@@ -605,6 +706,8 @@ int drone_vec_bytes_per_env_step(const DroneVec* v) {
     return 16 * (planes_read + planes_written) + 16 + 4 * drone_obs_dim(task) + 4 + 2;
 }
 
+const char* drone_vec_variant(const DroneVec* v) { return v ? v->variant : ""; }
+
 int drone_vec_host_transport(const DroneVec* v) {
     if (!v || !v->host_buffers) return -1;
     if (!v->zero_copy) return 0;
@@ -618,13 +721,16 @@ int drone_vec_host_pin(DroneVec* v, void* p, size_t bytes, int pages_exclusive) 
     Entry in(v);
     if (!in) return -1;
     if (!p || !bytes) { set_err("host_pin: NULL block or zero size"); return -1; }
-    if (already_pinned(p)) return 0;
+    if (already_pinned(p, bytes)) return 0;  // the owner's registration: used as it is, never dropped by host_unpin
     const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0, whole = (bytes % kPage) == 0;
     if (!aligned || !(whole || pages_exclusive)) {
         set_err("host_pin: the block must start on a 4 KiB boundary and span whole pages (or be vouched for: pages_exclusive), see DroneConfig.host_pages_exclusive");
         return -1;
     }
+    const int cap = (int)(sizeof(v->pinned_blocks) / sizeof(v->pinned_blocks[0]));
+    if (v->n_pinned_blocks >= cap) { set_err("host_pin: this handle already holds %d pinned blocks (unpin some first)", cap); return -1; }
     HIP_TRY(host_register(p, (bytes + kPage - 1) / kPage * kPage, v, "drone_vec_host_pin"), return -1);
+    v->pinned_blocks[v->n_pinned_blocks++] = p;
     return 0;
 }
 
@@ -632,7 +738,11 @@ int drone_vec_host_unpin(DroneVec* v, void* p) {
     Entry in(v);
     if (!in || !idle(v, "host_unpin")) return -1;
     if (!p) { set_err("host_unpin: NULL block"); return -1; }
+    int k = 0;
+    while (k < v->n_pinned_blocks && v->pinned_blocks[k] != p) k++;
+    if (k == v->n_pinned_blocks) return 0;  // not registered by host_pin on this handle (the caller's own pin, or never pinned): not ours to drop
     HIP_TRY(hipStreamSynchronize(v->stream), return -1);  // nothing of this handle may still be writing the block
+    v->pinned_blocks[k] = v->pinned_blocks[--v->n_pinned_blocks];
     HIP_TRY(hipHostUnregister(p), return -1);
     return 0;
 }
@@ -694,10 +804,15 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // (profiles/r03_ab/ab_dt_*.txt: -4.4 % at 2^19 envs, -5.2 % at 2^20, -6.4 % at 2^21, -4.7 % at 2^22; neutral at
         // 2^18 and +1.4 % at 131 072, where the step is bound by one or two waves per SIMD issuing VALU, not by bytes);
         // DRONE_DERIVED_TARGET=0/1 forces it (1 is ignored where the layout cannot represent the handle).
+        // Who decides: DRONE_DERIVED_TARGET (tuning tools) over DroneConfig.state_layout (the caller's declared choice) over
+        // the footprint rule.
         const bool can = task_has_derived_target(cfg->task) && cfg->horizon <= 65535;
         const char* e = getenv("DRONE_DERIVED_TARGET");
         const size_t per_step = (size_t)num_envs * 278u;
-        v->dv.derived_target = can && ((e && *e) ? (atoi(e) != 0) : (per_step >= ((size_t)100 << 20)));
+        if (e && *e) v->dv.derived_target = can && atoi(e) != 0;
+        else if (cfg->state_layout == DRONE_LAYOUT_DERIVED_TARGET) v->dv.derived_target = 1;  // validate() checked that it can
+        else if (cfg->state_layout == DRONE_LAYOUT_TARGET_PLANE) v->dv.derived_target = 0;
+        else v->dv.derived_target = can && per_step >= ((size_t)100 << 20);
     }
     const bool dt = v->dv.derived_target != 0;
     const size_t hot_elems = (size_t)v->n_pad * hot_planes(cfg->task, dt), cold_elems = (size_t)2 * v->stride;
@@ -815,6 +930,9 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
+    snprintf(v->variant, sizeof(v->variant), "drone_step_kernel<task=%d,compact=%d,stream=%d,dt=%d> order=%u line_complete=%u packed_rk4=%u bytes=%d",
+             cfg->task, v->dv.done_ids ? 1 : 0, (v->dv.order & 4u) ? 1 : 0, v->dv.derived_target ? 1 : 0, v->dv.order, v->dv.line_complete,
+             v->dv.packed_rk4, drone_vec_bytes_per_env_step(v));
 #undef INIT_TRY
     if (debug_reg()) fprintf(stderr, "[drone reg] init %p n=%d %s%s obs=%p act=%p planes=%p\n", (void*)v, v->n, v->host_buffers ? "host" : "device", v->zero_copy ? " zero-copy" : "", (void*)observations, (void*)actions, (void*)v->dv.planes);
     return v;
@@ -828,7 +946,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
     v->list_valid = false;
     v->many_k = 0;
-    if (!upload_params(v) || !push_counters(v)) return;
+    if (!upload_params(v) || !push_counters(v) || !peer_before_launch(v)) return;
     HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream), return);
     if (v->host_buffers) device_to_host_outputs(v);
 }
@@ -836,6 +954,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
 namespace {
 bool step_send_impl(DroneVec* v) {
     if (v->host_buffers && !host_to_device_actions(v)) return false;
+    if (!peer_before_launch(v)) return false;
     HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream), return false);
     v->gstep += 1;
     v->step_launches += 1;
@@ -869,6 +988,7 @@ void drone_vec_rollout(DroneVec* v, int horizon) {
     Entry in(v);
     if (!in || !idle(v, "rollout")) return;
     if (horizon <= 0) { set_err("rollout: horizon must be positive, got %d", horizon); return; }
+    if (!peer_before_launch(v)) return;
     HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream), return);
     v->gstep += (uint32_t)horizon;
     v->list_valid = false;  // the fused rollout builds no done-id list
@@ -943,8 +1063,9 @@ void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat,
     bool direct = false;
     if (v->host_buffers) {
         const char* zc = getenv("DRONE_HOST_ZEROCOPY");
-        if (!(zc && *zc && atoi(zc) == 0) && (!actions || already_pinned(actions)) && already_pinned(observations) && already_pinned(rewards) &&
-            already_pinned(terminals) && already_pinned(truncations)) {
+        const size_t act_bytes = (repeat ? 1 : K) * n * DRONE_ACT_DIM * sizeof(float);
+        if (!(zc && *zc && atoi(zc) == 0) && (!actions || already_pinned(actions, act_bytes)) && already_pinned(observations, K * n * od * sizeof(float)) &&
+            already_pinned(rewards, K * n * sizeof(float)) && already_pinned(terminals, K * n) && already_pinned(truncations, K * n)) {
             void* m[5] = {actions ? mapped_ptr(const_cast<float*>(actions)) : nullptr, mapped_ptr(observations), mapped_ptr(rewards), mapped_ptr(terminals), mapped_ptr(truncations)};
             direct = (!actions || m[0]) && m[1] && m[2] && m[3] && m[4] && !(reinterpret_cast<uintptr_t>(m[0]) & 15u) && !(reinterpret_cast<uintptr_t>(m[1]) & 15u) &&
                      !(reinterpret_cast<uintptr_t>(m[2]) & 3u);
@@ -997,8 +1118,10 @@ void drone_vec_log(DroneVec* v, DroneLog* out) {
         for (int k = 0; k < 6; k++) s[k] += v->h_partials[b * 6 + k];
     const double n = s[4];
     if (n > 0) {
-        out->perf = (float)(s[0] / n);
-        out->score = (float)(s[1] / n);
+        // SPEC.md section 8 (v5): hover / swarm episodes log the count of steps within hover_radius; reported per step flown
+        const bool per_step = v->cfg.task == DRONE_TASK_HOVER || v->cfg.task == DRONE_TASK_SWARM;
+        out->perf = (float)(s[0] / (per_step ? s[3] : n));
+        out->score = (float)(s[1] / (per_step ? s[3] : n));
         out->episode_return = (float)(s[2] / n);
         out->episode_length = (float)(s[3] / n);
         out->oob = (float)(s[5] / n);
@@ -1016,6 +1139,8 @@ void drone_vec_close(DroneVec* v) {
     gather_destroy(v);
     for (int i = 0; i < 5; i++)
         if (v->registered[i]) host_unregister(v->registered_ptr[i], v, "caller buffer at close");
+    for (int i = 0; i < v->n_pinned_blocks; i++) host_unregister(v->pinned_blocks[i], v, "drone_vec_host_pin block at close");
+    v->n_pinned_blocks = 0;
     (void)hipFree(v->dv.planes);
     (void)hipFree(v->dv.cold);
     (void)hipFree(v->d_kp);
@@ -1090,6 +1215,7 @@ int drone_vec_bind_outputs(DroneVec* v, float* observations, float* rewards, uns
     Entry in(v);
     if (!in || !idle(v, "bind_outputs")) return -1;
     if (!observations || !rewards || !terminals || !truncations) { set_err("bind_outputs: NULL argument"); return -1; }
+    if (v->gather && v->gather->peer) { set_err("bind_outputs: the peer-store exchange owns the output bindings (drone_vec_gather_close first)"); return -1; }
     if (!v->host_buffers) {
         if ((reinterpret_cast<uintptr_t>(observations) & 15u) || (reinterpret_cast<uintptr_t>(rewards) & 3u)) {
             set_err("device buffers must be 16-byte aligned (observations) and 4-byte aligned (rewards)");
@@ -1422,7 +1548,7 @@ int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, i
             const size_t bytes[4] = {g->total * od * sizeof(float), g->total * sizeof(float), g->total, g->total};
             for (int k = 0; k < 4; k++) {  // pinned only when the pages are the buffer's own (pin_caller_buffer's rule)
                 const bool own_pages = (reinterpret_cast<uintptr_t>(hosts[k]) % kPage) == 0 && ((bytes[k] % kPage) == 0 || v->cfg.host_pages_exclusive);
-                g->h_registered[k] = own_pages && !already_pinned(hosts[k]) &&
+                g->h_registered[k] = own_pages && !already_pinned(hosts[k], bytes[k]) &&
                                      host_register(hosts[k], (bytes[k] + kPage - 1) / kPage * kPage, v, "global gather buffer") == hipSuccess;
                 if (own_pages && !g->h_registered[k]) (void)hipGetLastError();
             }
@@ -1448,11 +1574,109 @@ int drone_vec_gather_init(DroneVec* v, const unsigned char* id, int rank, int wo
     return drone_vec_gather_init_root(v, id, rank, world, counts, -1, all_observations, all_rewards, all_terminals, all_truncations);
 }
 
+// ---- the same exchange as peer stores (round 4) ----
+namespace {
+struct PeerBuf {
+    hipIpcMemHandle_t handle;  // of the ALLOCATION the buffer lives in (a torch tensor sits somewhere inside a caching-allocator segment)
+    uint64_t offset;           // of the buffer inside it
+};
+static_assert(sizeof(PeerBuf) * 4 == DRONE_PEER_TOKEN_BYTES, "DRONE_PEER_TOKEN_BYTES must hold four IPC handles + offsets");
+}  // namespace
+
+int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* all_rewards, unsigned char* all_terminals,
+                                 unsigned char* all_truncations, unsigned char* token) {
+    Entry in(v);
+    if (!in || !idle(v, "gather_peer_export")) return -1;
+    if (v->host_buffers) { set_err("gather_peer_export: the peer-store exchange needs device buffers (peers write HBM, not host memory)"); return -1; }
+    if (!all_observations || !all_rewards || !all_terminals || !all_truncations || !token) { set_err("gather_peer_export: NULL argument"); return -1; }
+    if (reinterpret_cast<uintptr_t>(all_observations) & 15u) { set_err("gather_peer_export: global observations must be 16-byte aligned"); return -1; }
+    void* bufs[4] = {all_observations, all_rewards, all_terminals, all_truncations};
+    PeerBuf out[4];
+    memset(out, 0, sizeof(out));
+    for (int k = 0; k < 4; k++) {
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        HIP_TRY(hipMemGetAddressRange(&base, &size, bufs[k]), return -1);
+        HIP_TRY(hipIpcGetMemHandle(&out[k].handle, base), return -1);
+        out[k].offset = (uint64_t)(static_cast<char*>(bufs[k]) - static_cast<char*>(base));
+    }
+    memcpy(token, out, sizeof(out));
+    v->px_obs = all_observations; v->px_rew = all_rewards; v->px_term = all_terminals; v->px_trunc = all_truncations;
+    return 0;
+}
+
+int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* shared_flags, int rank, int world, const int* counts, int root) {
+    Entry in(v);
+    if (!in || !idle(v, "gather_init_peer")) return -1;
+    if (v->gather) { set_err("gather already initialised on this handle"); return -1; }
+    if (v->host_buffers) { set_err("gather_init_peer: the peer-store exchange needs device buffers"); return -1; }
+    if (!token || !shared_flags || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) { set_err("gather_init_peer: bad token / flags / rank %d / world %d / root %d", rank, world, root); return -1; }
+    if ((reinterpret_cast<uintptr_t>(shared_flags) % kPage) != 0 || (size_t)(world + 1) * 4u > kPage) { set_err("gather_init_peer: the flag block must be one 4 KiB page of memory shared by all ranks, page-aligned (world <= 1023)"); return -1; }
+    if (rank == root && !v->px_obs) { set_err("gather_init_peer: the root must export its global buffers first (drone_vec_gather_peer_export)"); return -1; }
+    Gather* g = new (std::nothrow) Gather();
+    if (!g) { set_err("out of memory"); return -1; }
+    g->peer = true;
+    g->rank = rank; g->world = world; g->root = root;
+    g->counts.resize(world);
+    g->offsets.resize(world);
+    for (int r = 0; r < world; r++) {
+        const int c = counts ? counts[r] : v->n;
+        if (c <= 0) { set_err("gather_init_peer: counts[%d] = %d", r, c); delete g; return -1; }
+        g->counts[r] = (size_t)c;
+        g->offsets[r] = g->total;
+        g->total += (size_t)c;
+    }
+    if (g->counts[rank] != (size_t)v->n) { set_err("gather_init_peer: counts[rank] = %zu but this handle has %d envs", g->counts[rank], v->n); delete g; return -1; }
+    g->own_obs = v->dv.obs; g->own_rew = v->dv.rew; g->own_term = v->dv.term; g->own_trunc = v->dv.trunc;
+    v->gather = g;  // from here on gather_destroy undoes whatever was done
+    // the flag page: pinned + mapped so that stream memory operations can reach it (it owns its page: the rule of pin_caller_buffer)
+    if (!already_pinned(shared_flags, kPage)) {
+        HIP_TRY(host_register(shared_flags, kPage, v, "peer-store flag page"), { gather_destroy(v); return -1; });
+        g->flags_registered = true;
+    }
+    g->flags = static_cast<volatile uint32_t*>(shared_flags);
+    g->d_flags = static_cast<char*>(mapped_ptr(shared_flags));
+    if (!g->d_flags) { set_err("gather_init_peer: the flag page could not be mapped into the device address space"); gather_destroy(v); return -1; }
+    const char* hw = getenv("DRONE_PEER_HOST_WAIT");
+    if (hw && *hw && atoi(hw) != 0) g->gpu_waits = false;
+    const size_t od = (size_t)drone_obs_dim(v->cfg.task), o = g->offsets[rank];
+    char* glob[4];
+    if (rank == root) {
+        glob[0] = reinterpret_cast<char*>(v->px_obs); glob[1] = reinterpret_cast<char*>(v->px_rew);
+        glob[2] = reinterpret_cast<char*>(v->px_term); glob[3] = reinterpret_cast<char*>(v->px_trunc);
+    } else {
+        PeerBuf in4[4];
+        memcpy(in4, token, sizeof(in4));
+        for (int k = 0; k < 4; k++) {
+            HIP_TRY(hipIpcOpenMemHandle(&g->peer_base[k], in4[k].handle, hipIpcMemLazyEnablePeerAccess), { gather_destroy(v); return -1; });
+            glob[k] = static_cast<char*>(g->peer_base[k]) + in4[k].offset;
+        }
+    }
+    g->g_obs = reinterpret_cast<float*>(glob[0]); g->g_rew = reinterpret_cast<float*>(glob[1]);
+    g->g_term = reinterpret_cast<unsigned char*>(glob[2]); g->g_trunc = reinterpret_cast<unsigned char*>(glob[3]);
+    // from now on this rank's kernels write ITS ROWS OF THE ROOT'S BUFFERS: local HBM on the root, xGMI stores elsewhere
+    v->dv.obs = g->g_obs + o * od;   // row offsets are multiples of 80 / 96 bytes: 16-byte alignment of the base carries over
+    v->dv.rew = g->g_rew + o;
+    v->dv.term = g->g_term + o;
+    v->dv.trunc = g->g_trunc + o;
+    if (reinterpret_cast<uintptr_t>(v->dv.obs) & 15u) { set_err("gather_init_peer: this rank's rows of the global observations are not 16-byte aligned"); gather_destroy(v); return -1; }
+    return 0;
+}
+
 int drone_vec_gather(DroneVec* v) {
     Entry in(v);
     if (!in || !idle(v, "gather")) return -1;
     Gather* g = v->gather;
     if (!g) { set_err("gather not initialised (drone_vec_gather_init)"); return -1; }
+    if (g->peer) {
+        // Peer stores: the rows are already where they belong (the kernels wrote them there). A non-root rank publishes
+        // "my launch #seq has landed" behind its kernel; the root's stream waits until every other rank has said so.
+        g->seq += 1u;
+        if (g->rank != g->root) return peer_post(v, g, g->rank, g->seq) ? 0 : -1;
+        for (int r = 0; r < g->world; r++)
+            if (r != g->root && !peer_wait_ge(v, g, r, g->seq)) return -1;
+        return 0;
+    }
     Rccl* R = rccl();
     if (!R) return -1;
     const size_t od = (size_t)drone_obs_dim(v->cfg.task);

@@ -104,6 +104,8 @@ class Drone:
         K = int(k_steps if actions is None else actions.shape[0])
         bufs = getattr(self, "_many", None)
         if bufs is None or bufs.k_steps != K:
+            if bufs is not None:
+                self.vec.free_step_many(bufs)  # a new K: the old pinned K x N host blocks must not stay registered until close
             bufs = self._many = self.vec.alloc_step_many(K)
         if actions is not None and actions is not bufs.actions:
             if self.vec.torch_device is None:

@@ -72,7 +72,19 @@ typedef struct DroneConfig {
      * own on-the-fly pinning of pageable copy destinations on that page ("Memory access fault by GPU ... on address
      * <heap address>", tools/debug/pageable_copy_stress.py reproduces it without this library). */
     int32_t host_pages_exclusive;
+    /* How the device keeps the state (round 4; ADVICE r3: the choice is part of the handle's declared contract, not only of
+     * its size). DRONE_LAYOUT_AUTO (0, default): hover / swarm handles whose step is HBM-bound (about 2^19 envs on) use the
+     * derived-target layout — no target plane, the target re-derived from (reset key, env, episode), 262 instead of 278
+     * bytes per env-step for hover — smaller ones keep the target plane. DRONE_LAYOUT_TARGET_PLANE / _DERIVED_TARGET force
+     * one (derived-target needs task 0 or 2 and horizon <= 65535; init fails otherwise). What differs for the caller:
+     * drone_vec_set_state on a derived-target handle refuses rows whose target is not the one SPEC.md section 6 draws for
+     * (env, episode) or whose counters exceed 65535; get_state, checkpoints and every trajectory are identical. */
+    int32_t state_layout;
 } DroneConfig;
+
+#define DRONE_LAYOUT_AUTO 0
+#define DRONE_LAYOUT_TARGET_PLANE 1
+#define DRONE_LAYOUT_DERIVED_TARGET 2
 
 /* Aggregated episode statistics since the previous drone_vec_log (SPEC.md §8). */
 typedef struct DroneLog {
@@ -104,6 +116,14 @@ int drone_device_count(void);
 /* Algorithmic HBM bytes the per-step kernel moves per env and step for THIS handle (task and state layout: hover 278, or
  * 262 when the handle uses the derived-target layout; waypoint / race 310; swarm 294 / 278) — what bench.py's roofline uses. */
 int drone_vec_bytes_per_env_step(const DroneVec* v);
+
+/* Which instantiation of the per-step kernel this handle launches and the per-handle launch choices, as text:
+ * "drone_step_kernel<task=0,compact=0,stream=0,dt=1> order=1 line_complete=0 packed_rk4=0 bytes=262" — task, done-id
+ * compaction, non-temporal action loads, derived-target layout (the four template arguments of drone_step_kernel), the
+ * sweep order, whole-line widening of rare plane updates, packed-f32 RK4 in the register-resident kernels, and the
+ * algorithmic bytes per env-step. Tests use it to assert that the sizes bench.py times run the instantiations the
+ * parity suite covers (tests/test_configs_gpu.py). The string lives in the handle. */
+const char* drone_vec_variant(const DroneVec* v);
 
 /* How host-buffer steps of this handle move their data: 1 = zero-copy (the kernel reads / writes the caller's pinned
  * buffers over PCIe); 2 = zero-copy through pinned stand-ins the library owns for those of the five buffers that could
@@ -175,6 +195,8 @@ void drone_vec_step_repeat(DroneVec* v, int k_steps, const float* actions, float
  * 4 KiB boundary and either span whole pages or be vouched for (pages_exclusive = 1: its own mmap / posix_memalign block
  * padded to whole pages). Unpin before freeing the block. 0 / -1 (drone_last_error). */
 int drone_vec_host_pin(DroneVec* v, void* block, size_t bytes, int pages_exclusive);
+/* Drops a registration drone_vec_host_pin made on this handle. A block host_pin found already pinned by its owner
+ * (hipHostMalloc / the caller's own hipHostRegister) was never registered here and is left alone: returns 0. */
 int drone_vec_host_unpin(DroneVec* v, void* block);
 
 void drone_vec_log(DroneVec* v, DroneLog* out);
@@ -278,6 +300,26 @@ int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, i
                                unsigned char* all_terminals, unsigned char* all_truncations);
 int drone_vec_gather(DroneVec* v);
 void drone_vec_gather_close(DroneVec* v);
+
+/* The same exchange WITHOUT a collective: peer stores (round 4). For one consumer process on rank `root` whose batch
+ * lives in HBM. The root exports its four global device buffers as IPC handles (drone_vec_gather_peer_export fills
+ * DRONE_PEER_TOKEN_BYTES bytes; ship them to the other ranks like the RCCL id); every rank then calls
+ * drone_vec_gather_init_peer. From then on each rank's kernels write observations / rewards / flags straight into that
+ * rank's rows of the ROOT's buffers — local HBM on the root, stores over xGMI everywhere else: no collective launch, no
+ * second pass over the outputs, nothing received or written by the other GPUs. drone_vec_gather is then only a
+ * handshake, one call per launch on every rank as with RCCL: a non-root rank publishes "my launch has landed" behind its
+ * kernel, the root's stream waits for all of them (hipStreamWriteValue32 / hipStreamWaitValue32 on `shared_flags`: ONE
+ * page-aligned 4 KiB page of host memory shared by all ranks — POSIX shm, or a MAP_SHARED mapping made before fork —
+ * zeroed by whoever creates it). Back-pressure: a rank's next launch waits until the root has begun ITS next launch,
+ * which it enqueues behind whatever consumed the batch on its stream. Device buffers only; bind_outputs is refused while
+ * it is active; drone_vec_gather_close gives the handle its own output buffers back. A dead peer: the waits are in the
+ * hardware queue by default and wait for ever — DRONE_PEER_HOST_WAIT=1 makes the host poll instead, bounded by
+ * DRONE_PEER_TIMEOUT_MS (default 10 000), and a timeout becomes an error on the handle. */
+#define DRONE_PEER_TOKEN_BYTES 288
+int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* all_rewards,
+                                 unsigned char* all_terminals, unsigned char* all_truncations, unsigned char* token);
+int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* shared_flags, int rank, int world,
+                               const int* counts, int root);
 
 /* HIP-event timer on the handle's stream: start, ..launches.., stop → ms. */
 int drone_vec_timer_start(DroneVec* v);

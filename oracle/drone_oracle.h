@@ -320,11 +320,15 @@ static inline void reset_state(Drone* env) {
         t[i] = c->tilt_init * val[6 + i];
     }
     const float n2 = fmaf(t[0], t[0], fmaf(t[1], t[1], fmaf(t[2], t[2], 1.0f)));
-    const float inv = 1.0f / sqrtf(n2);
-    env->s.quat[0] = inv;
-    env->s.quat[1] = t[0] * inv;
-    env->s.quat[2] = t[1] * inv;
-    env->s.quat[3] = t[2] * inv;
+    /* SPEC v5: two Newton steps of 1/sqrt(n2) about 1 — no square root, no division */
+    const float s1 = fmaf(-0.5f, n2, 1.5f);
+    const float m = (n2 * s1) * s1;
+    const float s2 = fmaf(-0.5f, m, 1.5f);
+    const float sc = s1 * s2;
+    env->s.quat[0] = sc;
+    env->s.quat[1] = t[0] * sc;
+    env->s.quat[2] = t[1] * sc;
+    env->s.quat[3] = t[2] * sc;
     for (int i = 0; i < 3; i++) {
         env->s.vel[i] = 0.0f;
         env->s.omega[i] = 0.0f;
@@ -482,14 +486,10 @@ static inline void step_finish(Drone* env, float nn_d2) {
     env->truncations[0] = (unsigned char)trunc;
 
     if (oob || trunc) {
-        float score, perf;
-        if (c->task != DRONE_TASK_WAYPOINT && c->task != DRONE_TASK_RACE) {
-            score = (float)env->score_count / (float)env->tick;
-            perf = score;
-        } else {
-            score = (float)env->score_count;
-            perf = env->score_count >= 8u ? 1.0f : (float)env->score_count * 0.125f;
-        }
+        /* SPEC v5: tasks 0 and 2 log the COUNT of steps within hover_radius; vec_log divides by the steps flown */
+        const float score = (float)env->score_count;
+        float perf = score;
+        if (c->task == DRONE_TASK_WAYPOINT || c->task == DRONE_TASK_RACE) perf = env->score_count >= 8u ? 1.0f : score * 0.125f;
         env->log.perf += perf;
         env->log.score += score;
         env->log.episode_return += env->ep_return;

@@ -203,8 +203,10 @@ void oracle_vec_log(OracleVec* v, DroneLog* out) {
     }
     memset(out, 0, sizeof(*out));
     if (n > 0) {
-        out->perf = (float)(perf / n);
-        out->score = (float)(score / n);
+        /* SPEC.md §8 (v5): hover / swarm report the share of logged steps within hover_radius */
+        const int per_step = v->cfg.task == DRONE_TASK_HOVER || v->cfg.task == DRONE_TASK_SWARM;
+        out->perf = (float)(perf / (per_step ? len : n));
+        out->score = (float)(score / (per_step ? len : n));
         out->episode_return = (float)(ret / n);
         out->episode_length = (float)(len / n);
         out->oob = (float)(oob / n);

@@ -150,7 +150,10 @@ def reset_draws(c, seed, env, episode, task):
     tgt = c["target_extent"] * np.stack(u[3:6], 1)
     t = c["tilt_init"] * np.stack(u[6:9], 1)
     quat = np.concatenate([np.ones((len(pos), 1)), t], 1)
-    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    n2 = (quat * quat).sum(1, keepdims=True)
+    s1 = 1.5 - 0.5 * n2          # SPEC v5: two Newton steps of 1/sqrt(n2) about 1 (not the exact unit vector)
+    s2 = 1.5 - 0.5 * (n2 * s1 * s1)
+    quat = quat * (s1 * s2)
     n = len(pos)
     out = {"pos": pos, "vel": np.zeros((n, 3)), "quat": quat, "omega": np.zeros((n, 3)), "rpm": np.full((n, 4), c["hover_rpm"]),
            "target": tgt, "wind": np.zeros((n, 3))}
@@ -273,7 +276,7 @@ def env_step(c, seed, task, st, actions, gstep, env_ids):
     done = oob | trunc
     logs = {k: st[k].copy() for k in ("perf_sum", "score_sum", "ret_sum", "len_sum", "n_sum", "oob_sum")}
     if task in (0, 2):
-        sc = score / np.maximum(tick, 1)
+        sc = score.astype(np.float64)   # SPEC v5: the count; vec_log divides by the steps flown
         perf = sc
     else:
         sc = score.astype(np.float64)
