@@ -11,6 +11,7 @@ OBS_DIM = 20
 OBS_DIM_MAX = 24
 ACT_DIM = 4
 GATHER_ID_BYTES = 128
+PEER_TOKEN_BYTES = 288
 TASK_HOVER = 0
 TASK_WAYPOINT = 1
 TASK_SWARM = 2
@@ -126,6 +127,8 @@ SYMBOLS = {
     "drone_gather_unique_id": (C.c_int, [_P]),
     "drone_vec_gather_init": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "drone_vec_gather_init_root": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    "drone_vec_gather_peer_export": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "drone_vec_gather_init_peer": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "drone_vec_gather": (C.c_int, [_P]),
     "drone_vec_gather_close": (None, [_P]),
     "drone_vec_get_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),

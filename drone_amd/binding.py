@@ -161,6 +161,8 @@ class DroneVec:
             self.truncations = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._seed = int(seed)
         self._pinned_blocks = []
+        self._gathered = None      # global buffers of an active exchange (kept alive here)
+        self._peer_flags = None
         self._h = self._f["drone_vec_init"](
             _ptr(self.observations), _ptr(self.actions), _ptr(self.rewards), _ptr(self.terminals), _ptr(self.truncations),
             n, seed, C.byref(self.cfg))
@@ -380,9 +382,31 @@ class DroneVec:
         self._check(self._f["drone_vec_gather"](self._h))
         return self._gathered
 
+    # -- the same exchange without a collective: peer stores (drone_vec_gather_peer_export / _init_peer) --
+    def gather_peer_export(self, all_observations, all_rewards, all_terminals, all_truncations):
+        """Root only: IPC handles of its four global device buffers as ``abi.PEER_TOKEN_BYTES`` opaque bytes; ship them to
+        the other ranks (any means), then every rank calls ``gather_init_peer``."""
+        tok = (C.c_ubyte * abi.PEER_TOKEN_BYTES)()
+        self._gathered = (all_observations, all_rewards, all_terminals, all_truncations)  # keep alive
+        self._check(self._f["drone_vec_gather_peer_export"](self._h, *[_ptr(b) for b in self._gathered], C.cast(tok, C.c_void_p)))
+        return bytes(tok)
+
+    def gather_init_peer(self, token, shared_flags, rank, world, root=0, counts=None):
+        """Every rank: from now on this handle's kernels write its rows of the ROOT's global buffers (xGMI stores on the
+        other GPUs), and ``gather()`` is only the handshake. ``shared_flags``: a page-aligned 4 KiB numpy uint32 array
+        (or anything with ``ctypes.data``) backed by memory all ranks share, zeroed by its creator. The handle's
+        ``observations`` / ``rewards`` / ``terminals`` / ``truncations`` attributes no longer name what the kernels write
+        until ``gather_close``."""
+        tokbuf = (C.c_ubyte * abi.PEER_TOKEN_BYTES).from_buffer_copy(bytes(token))
+        cnt = (C.c_int * world)(*[int(c) for c in counts]) if counts is not None else None
+        self._peer_flags = shared_flags  # keep the mapping alive
+        self._check(self._f["drone_vec_gather_init_peer"](self._h, C.cast(tokbuf, C.c_void_p), _ptr(shared_flags), int(rank), int(world),
+                                                           C.cast(cnt, C.c_void_p) if cnt is not None else None, int(root)))
+
     def gather_close(self):
         self._f["drone_vec_gather_close"](self._h)
         self._gathered = None
+        self._peer_flags = None
 
     def bind_actions(self, actions):
         self._check(self._f["drone_vec_bind_actions"](self._h, _ptr(actions)))

@@ -936,6 +936,29 @@ __global__ __launch_bounds__(kBlock) void drone_log_reduce_kernel(float4* __rest
     }
 }
 
+// =====================================================================
+// peer-store exchange: the flag handshake as two one-wave kernels (hipStreamWaitValue32 only accepts signal memory of
+// the calling process; these flags live in host memory that several processes share)
+// =====================================================================
+__global__ __launch_bounds__(64) void drone_flag_post_kernel(uint32_t* flag, uint32_t value) {
+    if (threadIdx.x == 0) {
+        __threadfence_system();  // the preceding kernels' stores (kernel boundary) and anything of ours: ahead of the flag
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flag, uint32_t want, uint32_t* err, unsigned long long budget_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        __builtin_amdgcn_s_sleep(64);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
+            __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
 StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     StepArgs a;
     a.v = v;
@@ -1034,6 +1057,18 @@ hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint
 hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gstep, hipStream_t s) {
     drop_stale_error();
     drone_fill_actions_kernel<<<dim3(grid_for(v.n)), dim3(kBlock), 0, s>>>(make_args(v, gstep), reinterpret_cast<float4*>(actions));
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s) {
+    drop_stale_error();
+    drone_flag_post_kernel<<<dim3(1), dim3(64), 0, s>>>(flag, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_wait(const uint32_t* flag, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s) {
+    drop_stale_error();
+    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flag, want, err, budget_ticks);
     return hipGetLastError();
 }
 

@@ -544,7 +544,10 @@ struct Gather {
     volatile uint32_t* flags = nullptr;  // the shared page: post[world] then ack
     char* d_flags = nullptr;             // its device address (hipStreamWriteValue32 / hipStreamWaitValue32)
     bool flags_registered = false;
-    bool gpu_waits = true;               // false once hipStreamWaitValue32 refused the flag memory: the host polls instead
+    bool gpu_waits = true;               // the handshake runs on the stream (two one-wave kernels); false (DRONE_PEER_HOST_WAIT=1): the host drains the stream and polls / stores
+    uint32_t* h_err = nullptr;           // pinned + mapped word a stream-side wait sets when it gave up (a dead peer)
+    uint32_t* d_err = nullptr;
+    unsigned long long budget_ticks = 0; // of the 100 MHz real-time counter
     uint32_t seq = 0;                    // rounds this rank has published (non-root) / collected (root)
     uint32_t acked = 0;                  // root: last round whose consumption it has announced
     float* own_obs = nullptr; float* own_rew = nullptr; unsigned char* own_term = nullptr; unsigned char* own_trunc = nullptr;  // the handle's output bindings before the exchange took them over
@@ -565,6 +568,7 @@ void gather_destroy(DroneVec* v) {
         for (int k = 0; k < 4; k++)
             if (g->peer_base[k]) (void)hipIpcCloseMemHandle(g->peer_base[k]);
         if (g->flags_registered) host_unregister(const_cast<uint32_t*>(g->flags), v, "peer-store flag page");
+        if (g->h_err) (void)hipHostFree(g->h_err);
     }
     void* hosts[4] = {g->h_obs, g->h_rew, g->h_term, g->h_trunc};
     for (int k = 0; k < 4; k++)
@@ -584,16 +588,18 @@ void gather_destroy(DroneVec* v) {
 // wrap after 2^32 rounds is harmless on the host path). On the stream where the hardware can wait for it
 // (hipStreamWaitValue32: the command processor polls the word, no host involvement); where it cannot, the host drains
 // the stream and polls, bounded by DRONE_PEER_TIMEOUT_MS (default 10 s) so that a dead peer is an error, not a hang.
+long peer_timeout_ms() {
+    const char* t = getenv("DRONE_PEER_TIMEOUT_MS");
+    return (t && *t) ? atol(t) : 10000;
+}
+
 bool peer_wait_ge(DroneVec* v, Gather* g, int slot, uint32_t want) {
-    if (g->gpu_waits) {
-        const hipError_t e = hipStreamWaitValue32(v->stream, g->d_flags + 4 * slot, want, hipStreamWaitValueGte, 0xFFFFFFFFu);
-        if (e == hipSuccess) return true;
-        (void)hipGetLastError();
-        g->gpu_waits = false;
+    if (g->gpu_waits) {  // one lane polls the shared word from the stream; gives up after the budget and says so in *d_err
+        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags + 4 * slot), want, g->d_err, g->budget_ticks, v->stream), return false);
+        return true;
     }
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
-    const char* t = getenv("DRONE_PEER_TIMEOUT_MS");
-    const long limit_ms = (t && *t) ? atol(t) : 10000;
+    const long limit_ms = peer_timeout_ms();
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint32_t spins = 0;; spins++) {
@@ -613,10 +619,21 @@ bool peer_wait_ge(DroneVec* v, Gather* g, int slot, uint32_t want) {
 
 // publish `value` in flag `slot` behind everything enqueued on the stream so far
 bool peer_post(DroneVec* v, Gather* g, int slot, uint32_t value) {
-    if (hipStreamWriteValue32(v->stream, g->d_flags + 4 * slot, value, 0) == hipSuccess) return true;
-    (void)hipGetLastError();
+    if (g->gpu_waits) {
+        HIP_TRY(launch_flag_post(reinterpret_cast<uint32_t*>(g->d_flags + 4 * slot), value, v->stream), return false);
+        return true;
+    }
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
     __atomic_store_n(g->flags + slot, value, __ATOMIC_RELEASE);
+    return true;
+}
+
+// a stream-side wait of an earlier round gave up: surface it on the next call instead of delivering a stale batch
+bool peer_check_err(Gather* g) {
+    if (g->h_err && __atomic_load_n(g->h_err, __ATOMIC_ACQUIRE) != 0u) {
+        set_err("peer-store exchange: a wait on the stream gave up after %ld ms (a rank died or did not call drone_vec_gather)", peer_timeout_ms());
+        return false;
+    }
     return true;
 }
 
@@ -627,6 +644,7 @@ bool peer_post(DroneVec* v, Gather* g, int slot, uint32_t value) {
 bool peer_before_launch(DroneVec* v) {
     Gather* g = v->gather;
     if (!g || !g->peer || g->seq == 0) return true;
+    if (!peer_check_err(g)) return false;
     if (g->rank == g->root) {
         if (g->acked != g->seq) {
             if (!peer_post(v, g, g->world, g->seq)) return false;
@@ -1639,6 +1657,15 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
     if (!g->d_flags) { set_err("gather_init_peer: the flag page could not be mapped into the device address space"); gather_destroy(v); return -1; }
     const char* hw = getenv("DRONE_PEER_HOST_WAIT");
     if (hw && *hw && atoi(hw) != 0) g->gpu_waits = false;
+    if (g->gpu_waits) {
+        void* he = nullptr;
+        HIP_TRY(hipHostMalloc(&he, 64, hipHostMallocMapped), { gather_destroy(v); return -1; });
+        g->h_err = static_cast<uint32_t*>(he);
+        *g->h_err = 0u;
+        g->d_err = static_cast<uint32_t*>(mapped_ptr(he));
+        if (!g->d_err) { set_err("gather_init_peer: the error word could not be mapped"); gather_destroy(v); return -1; }
+        g->budget_ticks = (unsigned long long)peer_timeout_ms() * 100000ull;  // s_memrealtime counts at 100 MHz
+    }
     const size_t od = (size_t)drone_obs_dim(v->cfg.task), o = g->offsets[rank];
     char* glob[4];
     if (rank == root) {
@@ -1671,6 +1698,7 @@ int drone_vec_gather(DroneVec* v) {
     if (g->peer) {
         // Peer stores: the rows are already where they belong (the kernels wrote them there). A non-root rank publishes
         // "my launch #seq has landed" behind its kernel; the root's stream waits until every other rank has said so.
+        if (!peer_check_err(g)) return -1;
         g->seq += 1u;
         if (g->rank != g->root) return peer_post(v, g, g->rank, g->seq) ? 0 : -1;
         for (int r = 0; r < g->world; r++)

@@ -308,13 +308,14 @@ void drone_vec_gather_close(DroneVec* v);
  * rank's rows of the ROOT's buffers — local HBM on the root, stores over xGMI everywhere else: no collective launch, no
  * second pass over the outputs, nothing received or written by the other GPUs. drone_vec_gather is then only a
  * handshake, one call per launch on every rank as with RCCL: a non-root rank publishes "my launch has landed" behind its
- * kernel, the root's stream waits for all of them (hipStreamWriteValue32 / hipStreamWaitValue32 on `shared_flags`: ONE
- * page-aligned 4 KiB page of host memory shared by all ranks — POSIX shm, or a MAP_SHARED mapping made before fork —
- * zeroed by whoever creates it). Back-pressure: a rank's next launch waits until the root has begun ITS next launch,
- * which it enqueues behind whatever consumed the batch on its stream. Device buffers only; bind_outputs is refused while
- * it is active; drone_vec_gather_close gives the handle its own output buffers back. A dead peer: the waits are in the
- * hardware queue by default and wait for ever — DRONE_PEER_HOST_WAIT=1 makes the host poll instead, bounded by
- * DRONE_PEER_TIMEOUT_MS (default 10 000), and a timeout becomes an error on the handle. */
+ * kernel, the root's stream waits for all of them — two one-wave kernels on `shared_flags`: ONE page-aligned 4 KiB page
+ * of host memory shared by all ranks (POSIX shm, or a MAP_SHARED mapping made before fork), zeroed by whoever creates
+ * it. (hipStreamWaitValue32 cannot do this: it accepts only the calling process's signal memory.) Back-pressure: a
+ * rank's next launch waits until the root has begun ITS next launch, which it enqueues behind whatever consumed the batch
+ * on its stream. Device buffers only; bind_outputs is refused while it is active; drone_vec_gather_close gives the handle
+ * its own output buffers back. A dead peer: every wait gives up after DRONE_PEER_TIMEOUT_MS (default 10 000) — the
+ * stream-side ones set a flag that fails the next call on the handle; DRONE_PEER_HOST_WAIT=1 moves the whole handshake
+ * to the host (the stream is drained, the host polls / stores), where the timeout is an immediate error. */
 #define DRONE_PEER_TOKEN_BYTES 288
 int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* all_rewards,
                                  unsigned char* all_terminals, unsigned char* all_truncations, unsigned char* token);

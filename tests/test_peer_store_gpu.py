@@ -1,0 +1,133 @@
+"""The host-boundary exchange WITHOUT a collective (round 4): peer stores. The root exports its global
+observation / reward / flag buffers as IPC handles; every other rank — another PROCESS — maps them and its step kernel's
+output stores land in the root's HBM directly; `drone_vec_gather` is only a handshake through a shared page of flags
+(two one-wave kernels on the stream, or the host with DRONE_PEER_HOST_WAIT=1). On the 1-GPU box the ranks share the device (IPC between processes works
+the same; what an 8-GPU node adds is that the stores cross xGMI): 2 and 3 processes, ragged shards, root first and last,
+20- and 24-float rows, per-step and fused launches — the root's batch after EVERY launch must be what one oracle run
+over all envs produces, bit for bit. Same pattern as tests/test_gather_multirank_gpu.py, without the RCCL test double."""
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys, time, zlib
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from drone_amd import abi, binding
+from drone_amd.dist import shard_range
+rank, world, total, task, steps, seed, root, rollout = (int(x) for x in sys.argv[1:9])
+tokfile, flagfile, out = sys.argv[9:12]
+dev = torch.device("cuda:0")
+off, cnt = shard_range(total, rank, world) if task != 2 else (rank * (total // world), total // world)
+od = abi.obs_dim(task)
+over = dict(horizon=20, env_offset=off)
+if task == 2: over.update(agents_per_env=8, collision_radius=0.5)
+v = binding.DroneVec(cnt, seed=seed, cfg=binding.default_config(task, **over), device=dev)
+flags = np.memmap(flagfile, dtype=np.uint32, mode="r+", shape=(1024,))   # one shared 4 KiB page (mmap: page-aligned)
+counts = [(shard_range(total, r, world)[1] if task != 2 else total // world) for r in range(world)]
+if rank == root:
+    g = (torch.zeros((total, od), dtype=torch.float32, device=dev), torch.zeros(total, dtype=torch.float32, device=dev),
+         torch.zeros(total, dtype=torch.uint8, device=dev), torch.zeros(total, dtype=torch.uint8, device=dev))
+    tok = v.gather_peer_export(*g)
+    with open(tokfile + ".tmp", "wb") as fh: fh.write(tok)
+    os.rename(tokfile + ".tmp", tokfile)
+else:
+    t0 = time.time()
+    while not os.path.exists(tokfile):
+        assert time.time() - t0 < 120
+        time.sleep(0.01)
+    tok = open(tokfile, "rb").read()
+v.gather_init_peer(tok, flags, rank, world, root=root, counts=counts)
+crc = 0
+def consume():
+    global crc
+    if rank != root: return
+    for t in g:  # stream-ordered copies behind the handshake's waits: the consumer of this round
+        crc = zlib.crc32(t.cpu().numpy().tobytes(), crc)
+v.reset(seed); v.gather(); consume()
+done = 0
+while done < steps:
+    if rollout:
+        v.rollout(rollout); done += rollout
+    else:
+        v.fill_random_actions(); v.step(); done += 1
+    v.gather(); consume()
+torch.cuda.synchronize()
+v.gather_close()
+# the handle has its own output buffers back: one more step must land THERE and leave the global batch alone
+before = g[0].clone() if rank == root else None
+v.fill_random_actions(); v.step(); torch.cuda.synchronize()
+if rank == root:
+    assert torch.equal(before, g[0]), "a step after gather_close still wrote the exported buffers"
+    np.savez(out, crc=np.uint32(crc), final_obs_own=v.observations.cpu().numpy())
+v.close()
+"""
+
+
+def run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env=None, skip_ranks=()):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    tokfile, out = str(tmp_path / "token"), str(tmp_path / "out.npz")
+    flagfile = f"/dev/shm/drone_peer_flags_{os.getpid()}_{abs(hash(str(tmp_path))) % 10**8}"  # tmpfs: plain shared memory behind a name
+    with open(flagfile, "wb") as fh:
+        fh.write(b"\0" * 4096)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    procs = {r: subprocess.Popen([sys.executable, str(script)] + [str(x) for x in (r, world, total, task, steps, seed, root, rollout)] + [tokfile, flagfile, out],
+                                 env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world) if r not in skip_ranks}
+    res = {}
+    try:
+        for r, p in procs.items():
+            so, se = p.communicate(timeout=120)
+            res[r] = (p.returncode, se)
+    finally:
+        for p in procs.values():
+            if p.poll() is None:
+                p.kill()
+        os.unlink(flagfile)
+    return res, out
+
+
+@pytest.mark.parametrize("world,total,task,root,rollout,host_wait", [(2, 8192, 0, 0, 0, 0), (3, 7001, 1, 2, 0, 0), (2, 4096, 2, 1, 0, 0), (3, 6001, 3, 0, 16, 0),
+                                                                    (2, 5000, 0, 0, 0, 1)])
+def test_peer_stores_land_every_ranks_rows_in_the_roots_batch(oracle, hip, tmp_path, world, total, task, root, rollout, host_wait):
+    steps, seed = 48, 23
+    res, out = run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env={"DRONE_PEER_HOST_WAIT": "1"} if host_wait else None)
+    assert all(rc == 0 for rc, _ in res.values()), "\n".join(f"--- rank {r}: rc {rc}\n{se[-1500:]}" for r, (rc, se) in res.items())
+    over = dict(horizon=20)
+    if task == 2:
+        over.update(agents_per_env=8, collision_radius=0.5)
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, **over), threads=4)
+    o.reset(seed)
+    crc = 0
+    for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+        crc = zlib.crc32(buf.tobytes(), crc)
+    done = 0
+    while done < steps:
+        if rollout:
+            o.rollout(rollout)
+            done += rollout
+        else:
+            o.fill_random_actions()
+            o.step()
+            done += 1
+        for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+            crc = zlib.crc32(buf.tobytes(), crc)
+    got = np.load(out)
+    assert int(got["crc"]) == crc, f"{world} ranks, root {root}: the root's batches differ from one oracle run over all {total} envs"
+
+
+@pytest.mark.parametrize("host_wait", [0, 1])
+def test_a_dead_peer_is_an_error_not_a_hang(hip, tmp_path, host_wait):
+    """Rank 1 never starts. The root's wait gives up after DRONE_PEER_TIMEOUT_MS: on the host (DRONE_PEER_HOST_WAIT=1) the
+    gather call itself fails; on the stream the polling lane gives up, sets the error word, and the next call on the
+    handle fails. Either way the failure sticks to the handle as an error and the process ends."""
+    res, _ = run_ranks(tmp_path, 2, 4096, 0, 4, 1, 0, 0, extra_env={"DRONE_PEER_HOST_WAIT": str(host_wait), "DRONE_PEER_TIMEOUT_MS": "400"}, skip_ranks=(1,))
+    rc, se = res[0]
+    assert rc != 0 and ("did not reach" in se or "gave up" in se), se[-2000:]
