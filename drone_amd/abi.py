@@ -135,6 +135,9 @@ SYMBOLS = {
     "drone_vec_set_state": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "drone_vec_done_list": (C.c_int, [_P, _P, C.c_int]),
     "drone_vec_done_list_at": (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    "drone_device_malloc": (_P, [C.c_int, C.c_size_t]),
+    "drone_device_free": (None, [C.c_int, _P]),
+    "drone_vec_copy_to_host": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "drone_vec_timer_start": (C.c_int, [_P]),
     "drone_vec_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "drone_last_error": (C.c_char_p, []),

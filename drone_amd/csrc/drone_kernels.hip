@@ -101,6 +101,10 @@
 #define DRONE_STAMP(k) do {} while (0)
 #endif
 
+#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 0: wherever the compiler sinks their scalar loads (three dependent scalar-memory round trips ahead of the state loads); 1: all in the kernel's first scalar batch (one round trip); 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count: none). Round 4
+#define DRONE_EARLY_ARGS 2
+#endif
+
 #ifndef DRONE_CARRY_ROTOR  // 1: the register-resident kernels carry the rotor inputs from step to step (Lane::u); 0: recompute them every step (A/B only)
 #define DRONE_CARRY_ROTOR 1
 #endif
@@ -296,6 +300,7 @@ struct StepArgs {
     uint32_t gstep;
     uint32_t flags_aligned;  // bit0: terminals 16-B aligned, bit1: truncations 16-B aligned
     uint32_t done_slot;      // which of the two done-list counters this step launch adds to (the host alternates per STEP launch)
+    uint32_t nwg;            // workgroups of this launch (= gridDim.x, which the kernel would otherwise fetch from the hidden arguments in a scalar round trip of its own)
 #if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     KParams kp;              // constants by value: scalar loads from the kernarg segment
 #endif
@@ -513,15 +518,15 @@ __device__ __forceinline__ void advance_counters(const StepArgs& a, const Counte
 // bit 1 (odd steps only): sweep in reverse, so the
 // lines touched last in one step are the first touched in the next and are still in the Infinity Cache.
 // Bijective for any grid size; a speed choice only (profiles/r02_ab/ab_zz_*.txt, ab_order_*.txt).
-__device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep) {
+__device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uint32_t nwg) {
     uint32_t c = blockIdx.x;
 #if DRONE_XCD_REMAP
     if (order & 1u) {
-        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        const uint32_t xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
         c = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
 #endif
-    if ((order & 2u) && (gstep & 1u)) c = gridDim.x - 1u - c;
+    if ((order & 2u) && (gstep & 1u)) c = nwg - 1u - c;
     return c;
 }
 
@@ -539,10 +544,33 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep) {
 // =====================================================================
 // per-step kernel (SPEC.md §5): configs 1–4
 // =====================================================================
+// The leading scalar arguments repeat the words of `a` that the state-load addresses depend on. Built with
+// -mllvm -amdgpu-kernarg-preload-count (Makefile) they arrive in SGPRs with the wave — no scalar load, no wait — so the
+// state loads go out a scalar-memory round trip earlier (DRONE_EARLY_ARGS=2; firmware without kernarg preloading runs the
+// compatibility prologue the compiler emits, which loads them the old way).
+#define DRONE_STEP_PRE_PARAMS const float4* __restrict__ pre_planes, const float* __restrict__ pre_act, const uint32_t* __restrict__ pre_ctr, uint32_t pre_n, uint32_t pre_n_pad, \
+                              uint32_t pre_order, uint32_t pre_nwg, uint32_t pre_gstep, uint32_t pre_slot
+
 template <int TASK, bool COMPACT, bool STREAM, bool DT>
-__global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a) {
+__global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
+#if DRONE_EARLY_ARGS == 2
+    a.v.planes = const_cast<float4*>(pre_planes); a.v.act = pre_act; a.v.ctr = const_cast<uint32_t*>(pre_ctr);
+    a.v.n = pre_n; a.v.n_pad = pre_n_pad; a.v.order = pre_order; a.nwg = pre_nwg; a.gstep = pre_gstep; a.done_slot = pre_slot;
+#elif DRONE_EARLY_ARGS
+    // A wave's first microsecond at small shards is its prologue: the state loads cannot go out before the scalar loads
+    // of the words their addresses depend on have come back, and the compiler sank some of those (the plane pointers, the
+    // hidden-argument grid size) behind branches — three dependent scalar-memory round trips. Naming them all here makes
+    // them part of the one batch the kernel opens with (the empty asm needs them in SGPRs at this point).
+    {
+        const float4* p0 = a.v.planes;
+        const float* p1 = a.v.act;
+        const uint32_t* p2 = a.v.ctr;
+        uint32_t w0 = a.v.n, w1 = a.v.n_pad, w2 = a.v.order, w3 = a.nwg, w4 = a.gstep, w5 = a.done_slot, w6 = a.v.stride;
+        asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(w4), "s"(w5), "s"(w6));
+    }
+#endif
     const uint32_t n = a.v.n, np = a.v.stride, n_pad = a.v.n_pad;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float4* const tile = sh.obs_tile[threadIdx.x / kWave];
@@ -550,7 +578,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     // and hold a valid reset state: they load and compute like the rest and store nothing.
     const Counters ctr = read_counters(a);
     const uint32_t gstep = ctr.gstep, done_slot = ctr.launches & 1u;
-    uint32_t block_base = my_chunk(a.v.order, gstep) * (uint32_t)(DRONE_STEP_TILES * kBlock);
+    uint32_t block_base = my_chunk(a.v.order, gstep, a.nwg) * (uint32_t)(DRONE_STEP_TILES * kBlock);
 #if DRONE_STAMPS
     unsigned long long stamp_[kStampSlots];
     stamp_[8] = __builtin_amdgcn_s_memrealtime();
@@ -558,6 +586,11 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(StepArgs a)
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
     load_raw<TASK, STREAM, DT>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
+#if DRONE_EARLY_ARGS == 2
+    // everything above came out of preloaded SGPRs: the state loads are in flight before the kernel's first scalar-memory
+    // wait. Nothing may be scheduled across this point (a hoisted s_load + s_waitcnt, or a load sunk below one).
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
 #pragma unroll
     for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
@@ -706,7 +739,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     const uint32_t n = a.v.n, np = a.v.stride;
     const Counters ctr = read_counters(a);
     const uint32_t gstep0 = ctr.gstep;
-    const uint32_t block_base = my_chunk(a.v.order & 1u, 0u) * kBlock;
+    const uint32_t block_base = my_chunk(a.v.order & 1u, 0u, a.nwg) * kBlock;
     const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
     Lane L;
@@ -868,7 +901,7 @@ __global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m)
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
     const Counters ctr = read_counters(a);
-    const uint32_t block_base = my_chunk(a.v.order & 1u, 0u) * kBlock;
+    const uint32_t block_base = my_chunk(a.v.order & 1u, 0u, a.nwg) * kBlock;
     const uint32_t i = block_base + threadIdx.x;
     Lane L;
     const bool dt = a.v.derived_target != 0;
@@ -964,6 +997,7 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     a.v = v;
     a.gstep = gstep;
     a.done_slot = 0;
+    a.nwg = 0;  // set by the launchers that deal chunks (step, rollout, step_many)
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
 #if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     a.kp = *v.kp_host;
@@ -998,12 +1032,14 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     StepArgs a = make_args(v, gstep);
     a.done_slot = done_slot & 1u;
     const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
+    a.nwg = g.x;
     const bool compact = v.done_ids != nullptr;
     const bool stream = (v.order & 4u) != 0 || DRONE_NT_ACTION_LOADS;  // non-temporal action loads: HBM-only footprints
+#define DRONE_PRE_ARGS a.v.planes, a.v.act, a.v.ctr, a.v.n, a.v.n_pad, a.v.order, a.nwg, a.gstep, a.done_slot
 #define DRONE_LAUNCH_STEP2(T, D)                                                             \
     do {                                                                                     \
-        if (compact) { if (stream) drone_step_kernel<T, true, true, D><<<g, b, 0, s>>>(a); else drone_step_kernel<T, true, false, D><<<g, b, 0, s>>>(a); } \
-        else { if (stream) drone_step_kernel<T, false, true, D><<<g, b, 0, s>>>(a); else drone_step_kernel<T, false, false, D><<<g, b, 0, s>>>(a); }    \
+        if (compact) { if (stream) drone_step_kernel<T, true, true, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); else drone_step_kernel<T, true, false, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); } \
+        else { if (stream) drone_step_kernel<T, false, true, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); else drone_step_kernel<T, false, false, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); }    \
     } while (0)
 #define DRONE_LAUNCH_STEP(T) DRONE_LAUNCH_STEP2(T, false)
     const bool dt = v.derived_target != 0;
@@ -1013,13 +1049,15 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     else DRONE_LAUNCH_STEP(DRONE_TASK_WAYPOINT);
 #undef DRONE_LAUNCH_STEP2
 #undef DRONE_LAUNCH_STEP
+#undef DRONE_PRE_ARGS
     return hipGetLastError();
 }
 
 hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s) {
     drop_stale_error();
-    const StepArgs a = make_args(v, gstep0);
+    StepArgs a = make_args(v, gstep0);
     const dim3 g(grid_for(v.n)), b(kBlock);
+    a.nwg = g.x;
     const bool pk = use_packed(v);
 #define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon); } while (0)
     if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_HOVER);
@@ -1033,7 +1071,8 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
 hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint32_t k_steps, const float* act, uint32_t act_stride, float* obs, float* rew,
                             unsigned char* term, unsigned char* trunc, uint32_t* done_ids, uint32_t* done_count, hipStream_t s) {
     drop_stale_error();
-    const StepArgs a = make_args(v, gstep0);
+    StepArgs a = make_args(v, gstep0);
+    a.nwg = grid_for(v.n);
     ManyArgs m;
     m.act = act; m.act_stride = act_stride; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
     m.done_ids = done_ids; m.done_count = done_count; m.k_steps = k_steps;

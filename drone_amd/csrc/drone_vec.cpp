@@ -1480,6 +1480,33 @@ int drone_vec_done_list_at(DroneVec* v, int k, uint32_t* ids, int cap) {
     return fetch_done_list(v, v->many_count + k, v->many_ids + (size_t)k * (size_t)v->n, ids, cap);
 }
 
+void* drone_device_malloc(int device, size_t bytes) {
+    g_err[0] = 0;
+    DeviceRestore restore;
+    void* p = nullptr;
+    HIP_TRY(hipSetDevice(device), return nullptr);
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 1), return nullptr);
+    HIP_TRY(hipMemset(p, 0, bytes ? bytes : 1), { (void)hipFree(p); return nullptr; });
+    return p;
+}
+
+void drone_device_free(int device, void* p) {
+    if (!p) return;
+    DeviceRestore restore;
+    if (hipSetDevice(device) == hipSuccess) (void)hipFree(p);
+    else (void)hipGetLastError();
+}
+
+int drone_vec_copy_to_host(DroneVec* v, void* host_dst, const void* device_src, size_t bytes) {
+    Entry in(v);
+    if (!in) return -1;
+    if (!host_dst || !device_src) { set_err("copy_to_host: NULL argument"); return -1; }
+    HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, v->stream), return -1);
+    HIP_TRY(hipStreamSynchronize(v->stream), return -1);
+    if (v->gather && v->gather->peer && !peer_check_err(v->gather)) return -1;  // a wait ahead of this copy gave up: the batch is not this round's
+    return 0;
+}
+
 int drone_vec_timer_start(DroneVec* v) {
     Entry in(v);
     if (!in) return -1;

@@ -8,7 +8,7 @@
  * here: both stay behind the C-ABI.
  *
  *   drone_host_mp [--gpus G] [--envs TOTAL] [--steps K] [--task 0..3] [--seed S]
- *                 [--gather 0|1] [--root R] [--rollout T] [--crc 1] [--share-devices 1] [--timeout SECONDS]
+ *                 [--gather 0|1] [--root R] [--exchange rccl|peer] [--rollout T] [--crc 1] [--share-devices 1] [--timeout SECONDS]
  *
  * Rank r takes envs [offset_r, offset_r + count_r) (the first TOTAL % G ranks get
  * one more) on device r. The RCCL unique id is made by rank 0 AFTER the fork and
@@ -19,6 +19,11 @@
  * gathered batch, which tests/test_c_host.py compares with the CPU oracle's.
  * --root R (default -1): -1 = all-gather, every rank ends up with the whole batch; R >= 0 = gather to rank R only
  *   (ncclSend / ncclRecv): the batch lands in rank R's host buffers, the printed CRC is rank R's.
+ * --exchange peer (round 4): the exchange WITHOUT a collective. Device buffers; rank R (--root, default 0) owns the batch
+ *   in its HBM and exports it (drone_vec_gather_peer_export: IPC handles through the shared page); every other rank's step
+ *   kernel stores its rows straight into it (xGMI on a multi-GPU node), drone_vec_gather is a flag handshake on a second
+ *   shared page. The root copies each batch to its host buffers for the CRC (its stand-in consumer). Works with several
+ *   ranks on ONE GPU too (--share-devices 1): the IPC mapping and the handshake are the same, only the stores stay local.
  * --rollout T: fused T-step rollouts with the gather once per horizon (configs[4]).
  * --share-devices 1: rank r uses device r %% (visible devices) — lets the fork / shard / barrier logic run with several
  *   ranks on a one-GPU box (without --gather: RCCL refuses two ranks on one device); every rank's CRC over ITS OWN
@@ -52,6 +57,8 @@ static void* page_alloc(size_t bytes) {
 
 typedef struct Shared {
     volatile int id_ready;
+    volatile int token_ready;
+    unsigned char token[DRONE_PEER_TOKEN_BYTES]; /* --exchange peer: the root's exported batch */
     volatile int failed;
     unsigned char id[DRONE_GATHER_ID_BYTES];
     volatile int arrived[2]; /* sense-reversing barrier over the ranks */
@@ -103,9 +110,119 @@ static int barrier(Shared* sh, int world, int* local_sense) {
 }
 
 typedef struct Opts {
-    int gpus, total, steps, task, gather, rollout, crc, share, timeout, die_rank, root;
+    int gpus, total, steps, task, gather, rollout, crc, share, timeout, die_rank, root, peer;
     unsigned long long seed;
 } Opts;
+
+/* --exchange peer: one rank's whole run. Device-buffer handle with library-owned local buffers; the root's global batch
+ * lives in its HBM (drone_device_malloc) and is copied to the host after every gather for the CRC. */
+static int run_rank_peer(const Opts* o, int rank, Shared* sh, void* flag_page) {
+    const int world = o->gpus, root = o->root;
+    int counts[64], offsets[64];
+    for (int r = 0, off = 0; r < world; r++) {
+        counts[r] = o->total / world + (r < o->total % world ? 1 : 0);
+        offsets[r] = off;
+        off += counts[r];
+    }
+    const int n = counts[rank];
+    const size_t od = (size_t)drone_obs_dim(o->task), total = (size_t)o->total;
+    DroneConfig cfg;
+    drone_config_default(&cfg, o->task);
+    cfg.buffer_kind = DRONE_BUFFERS_DEVICE;
+    cfg.device = rank;
+    if (o->share) {
+        const int ndev = drone_device_count();
+        if (ndev < 1) { fprintf(stderr, "rank %d: no HIP device\n", rank); return 1; }
+        cfg.device = rank % ndev;
+    }
+    cfg.env_offset = (uint32_t)offsets[rank];
+    DroneVec* v = drone_vec_init(NULL, NULL, NULL, NULL, NULL, n, o->seed, &cfg); /* library-owned HBM buffers */
+    if (!v) { fprintf(stderr, "rank %d: drone_vec_init failed: %s\n", rank, drone_last_error()); return 1; }
+    float* act = NULL;
+    drone_vec_buffers(v, NULL, &act, NULL, NULL, NULL);
+    float *g_obs = NULL, *g_rew = NULL, *h_obs = NULL, *h_rew = NULL;
+    unsigned char *g_term = NULL, *g_trunc = NULL, *h_term = NULL, *h_trunc = NULL;
+    if (rank == root) {
+        g_obs = (float*)drone_device_malloc(cfg.device, sizeof(float) * total * od);
+        g_rew = (float*)drone_device_malloc(cfg.device, sizeof(float) * total);
+        g_term = (unsigned char*)drone_device_malloc(cfg.device, total);
+        g_trunc = (unsigned char*)drone_device_malloc(cfg.device, total);
+        h_obs = (float*)page_alloc(sizeof(float) * total * od);
+        h_rew = (float*)page_alloc(sizeof(float) * total);
+        h_term = (unsigned char*)page_alloc(total);
+        h_trunc = (unsigned char*)page_alloc(total);
+        if (!g_obs || !g_rew || !g_term || !g_trunc || !h_obs || !h_rew || !h_term || !h_trunc) { fprintf(stderr, "rank %d: out of memory (%s)\n", rank, drone_last_error()); return 1; }
+        unsigned char token[DRONE_PEER_TOKEN_BYTES];
+        if (drone_vec_gather_peer_export(v, g_obs, g_rew, g_term, g_trunc, token) != 0) { fprintf(stderr, "rank %d: peer export failed: %s\n", rank, drone_last_error()); return 1; }
+        memcpy((void*)sh->token, token, sizeof(token));
+        __sync_synchronize();
+        sh->token_ready = 1;
+    } else {
+        while (!sh->token_ready) {
+            if (sh->failed || now_s() > sh->deadline) { fprintf(stderr, "rank %d: gave up waiting for the root's export\n", rank); return 1; }
+            usleep(100);
+        }
+    }
+    unsigned char token[DRONE_PEER_TOKEN_BYTES];
+    memcpy(token, (const void*)sh->token, sizeof(token));
+    if (drone_vec_gather_init_peer(v, token, flag_page, rank, world, counts, root) != 0) {
+        fprintf(stderr, "rank %d: drone_vec_gather_init_peer failed: %s\n", rank, drone_last_error());
+        return 1;
+    }
+    int sense = 0;
+    if (rank == o->die_rank) raise(SIGKILL);
+    uint32_t crc = 0;
+#define CONSUME(first)                                                                                                       \
+    do {                                                                                                                     \
+        if (rank == root && o->crc) { /* the root's consumer: the batch, behind the handshake's waits on the same stream */   \
+            if (drone_vec_copy_to_host(v, h_obs, g_obs, sizeof(float) * total * od) != 0 || ((first) ? 0 :                    \
+                (drone_vec_copy_to_host(v, h_rew, g_rew, sizeof(float) * total) != 0 || drone_vec_copy_to_host(v, h_term, g_term, total) != 0 || \
+                 drone_vec_copy_to_host(v, h_trunc, g_trunc, total) != 0))) { fprintf(stderr, "rank %d: %s\n", rank, drone_last_error()); return 1; } \
+            crc = crc32_update(crc, h_obs, sizeof(float) * total * od);                                                       \
+            if (!(first)) { crc = crc32_update(crc, h_rew, sizeof(float) * total); crc = crc32_update(crc, h_term, total); crc = crc32_update(crc, h_trunc, total); } \
+        }                                                                                                                    \
+    } while (0)
+    drone_vec_reset(v, o->seed);
+    if (drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
+    CONSUME(1);
+    const int launches = o->rollout > 0 ? (o->steps + o->rollout - 1) / o->rollout : o->steps;
+    if (barrier(sh, world, &sense)) { fprintf(stderr, "rank %d: start barrier abandoned\n", rank); return 1; }
+    const double t0 = now_s();
+    for (int t = 0; t < launches; t++) {
+        if (o->rollout > 0) {
+            drone_vec_rollout(v, o->rollout);
+        } else {
+            drone_vec_fill_random_actions(v, act, drone_vec_gstep(v));
+            drone_vec_step(v);
+        }
+        if (drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
+        CONSUME(0);
+    }
+#undef CONSUME
+    if (drone_vec_sync(v) != 0) { fprintf(stderr, "rank %d: %s\n", rank, drone_last_error()); return 1; }
+    sh->batch_crc[rank] = crc;
+    sh->rank_crc[rank] = 0;
+    sh->rank_seconds[rank] = now_s() - t0;
+    if (drone_vec_status(v)) { fprintf(stderr, "rank %d: %s\n", rank, drone_vec_status_message(v)); return 1; }
+    if (barrier(sh, world, &sense)) { fprintf(stderr, "rank %d: end barrier abandoned\n", rank); return 1; }
+    if (rank == 0) {
+        double el = 0;
+        for (int r = 0; r < world; r++) el = sh->rank_seconds[r] > el ? sh->rank_seconds[r] : el;
+        const double env_steps = (double)o->total * (o->rollout > 0 ? (double)o->rollout : 1.0) * launches;
+        printf("{\"mode\": \"%s + peer-store gather into rank %d's HBM batch (no collective)%s\", \"gpus\": %d, \"root\": %d, \"task\": %d, \"envs\": %d, \"launches\": %d, "
+               "\"horizon\": %d, \"env_steps_per_s\": %.4g, \"ms_per_launch\": %.4f, \"crc32\": %u}\n",
+               o->rollout > 0 ? "fused rollout" : "per-step", root, o->crc ? ", batch copied to the host and CRC'd every launch" : "", world, root, o->task, o->total, launches,
+               o->rollout, env_steps / el, el * 1e3 / launches, sh->batch_crc[root]);
+        fflush(stdout);
+    }
+    drone_vec_gather_close(v);
+    drone_vec_close(v);
+    if (rank == root) {
+        drone_device_free(cfg.device, g_obs); drone_device_free(cfg.device, g_rew); drone_device_free(cfg.device, g_term); drone_device_free(cfg.device, g_trunc);
+        free(h_obs); free(h_rew); free(h_term); free(h_trunc);
+    }
+    return 0;
+}
 
 static int run_rank(const Opts* o, int rank, Shared* sh) {
     const int world = o->gpus;
@@ -219,7 +336,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
 }
 
 int main(int argc, char** argv) {
-    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 300, -1, -1, 0ull};
+    Opts o = {1, 65536, 100, DRONE_TASK_HOVER, 1, 0, 0, 0, 300, -1, -1, 0, 0ull};
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--gpus")) o.gpus = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--envs")) o.total = atoi(argv[i + 1]);
@@ -230,6 +347,10 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--crc")) o.crc = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--share-devices")) o.share = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--root")) o.root = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "--exchange")) {
+            if (!strcmp(argv[i + 1], "peer")) o.peer = 1;
+            else if (strcmp(argv[i + 1], "rccl")) { fprintf(stderr, "--exchange must be rccl or peer\n"); return 2; }
+        }
         else if (!strcmp(argv[i], "--timeout")) o.timeout = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--die-rank")) o.die_rank = atoi(argv[i + 1]); /* tests: that rank kills itself before the start barrier */
         else if (!strcmp(argv[i], "--seed")) o.seed = strtoull(argv[i + 1], NULL, 10);
@@ -239,6 +360,7 @@ int main(int argc, char** argv) {
     if (o.gpus < 1 || o.gpus > 64 || o.total < o.gpus || o.steps < 1 || o.rollout < 0) { fprintf(stderr, "bad --gpus / --envs / --steps / --rollout\n"); return 2; }
     if (o.root < -1 || o.root >= o.gpus) { fprintf(stderr, "--root must be -1 or a rank\n"); return 2; }
     if (o.task < 0 || o.task > 3) { fprintf(stderr, "unknown task %d\n", o.task); return 2; }
+    if (o.peer && o.root < 0) o.root = 0; /* the peer-store exchange always has one owner of the batch */
     if (o.task == DRONE_TASK_SWARM && (o.total % (8 * o.gpus))) { fprintf(stderr, "swarm task: --envs must be a multiple of 8 x --gpus\n"); return 2; }
 
     /* One node by construction (one process per local GPU): let RCCL's bootstrap use the loopback interface unless the
@@ -249,13 +371,17 @@ int main(int argc, char** argv) {
     if (sh == MAP_FAILED) { perror("mmap"); return 1; }
     memset(sh, 0, sizeof(*sh));
     sh->deadline = now_s() + (double)o.timeout;
+    /* --exchange peer: the flag page of the handshake, a page of its own shared by all ranks (same rule: before the fork) */
+    void* flag_page = mmap(NULL, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (flag_page == MAP_FAILED) { perror("mmap"); return 1; }
+    memset(flag_page, 0, 4096);
     pid_t pids[64];
     int started = 0;
     for (int r = 0; r < o.gpus; r++) {
         pids[r] = fork();
         if (pids[r] < 0) { perror("fork"); sh->failed = 1; break; }
         if (pids[r] == 0) {
-            const int rc = run_rank(&o, r, sh);
+            const int rc = o.peer ? run_rank_peer(&o, r, sh, flag_page) : run_rank(&o, r, sh);
             if (rc) sh->failed = 1;
             fflush(stdout);
             _exit(rc);

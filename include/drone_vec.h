@@ -322,6 +322,13 @@ int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* al
 int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* shared_flags, int rank, int world,
                                const int* counts, int root);
 
+/* For hosts that stay plain C (no HIP headers): raw, zeroed device memory on a HIP device — e.g. the root's global buffers
+ * of the peer-store exchange — and a copy from device memory to the host, enqueued on the handle's stream behind its
+ * work (so behind a drone_vec_gather's waits) and complete on return. */
+void* drone_device_malloc(int device, size_t bytes);
+void drone_device_free(int device, void* p);
+int drone_vec_copy_to_host(DroneVec* v, void* host_dst, const void* device_src, size_t bytes);
+
 /* HIP-event timer on the handle's stream: start, ..launches.., stop → ms. */
 int drone_vec_timer_start(DroneVec* v);
 int drone_vec_timer_stop(DroneVec* v, float* elapsed_ms);

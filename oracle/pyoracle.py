@@ -27,7 +27,7 @@ _NOT_IN_ORACLE = (
     "drone_vec_set_stream", "drone_vec_sync", "drone_vec_bind_actions", "drone_vec_bind_outputs", "drone_vec_done_list",
     "drone_vec_timer_start", "drone_vec_timer_stop", "drone_last_error", "drone_device_count", "drone_vec_set_gstep", "drone_vec_enable_graph_capture", "drone_vec_status",
     "drone_vec_status_message", "drone_vec_clear_status", "drone_gather_unique_id", "drone_vec_gather_init",
-    "drone_vec_gather", "drone_vec_gather_close", "drone_vec_step_many", "drone_vec_step_repeat", "drone_vec_done_list_at", "drone_vec_gather_init_root", "drone_vec_host_transport", "drone_vec_bytes_per_env_step", "drone_vec_buffers", "drone_vec_device", "drone_vec_step_send", "drone_vec_step_recv", "drone_vec_host_pin", "drone_vec_host_unpin", "drone_vec_variant", "drone_vec_gather_peer_export", "drone_vec_gather_init_peer")
+    "drone_vec_gather", "drone_vec_gather_close", "drone_vec_step_many", "drone_vec_step_repeat", "drone_vec_done_list_at", "drone_vec_gather_init_root", "drone_vec_host_transport", "drone_vec_bytes_per_env_step", "drone_vec_buffers", "drone_vec_device", "drone_vec_step_send", "drone_vec_step_recv", "drone_vec_host_pin", "drone_vec_host_unpin", "drone_vec_variant", "drone_vec_gather_peer_export", "drone_vec_gather_init_peer", "drone_device_malloc", "drone_device_free", "drone_vec_copy_to_host")
 
 
 def _host_signature():

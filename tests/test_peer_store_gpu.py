@@ -131,3 +131,46 @@ def test_a_dead_peer_is_an_error_not_a_hang(hip, tmp_path, host_wait):
     res, _ = run_ranks(tmp_path, 2, 4096, 0, 4, 1, 0, 0, extra_env={"DRONE_PEER_HOST_WAIT": str(host_wait), "DRONE_PEER_TIMEOUT_MS": "400"}, skip_ranks=(1,))
     rc, se = res[0]
     assert rc != 0 and ("did not reach" in se or "gave up" in se), se[-2000:]
+
+
+EXE_MP = os.path.join(ROOT, "host", "drone_host_mp")
+
+
+@pytest.mark.parametrize("ranks,envs,task,rollout,root", [(2, 6000, 0, 0, 0), (3, 10001, 1, 0, 2), (3, 6144, 2, 16, 1), (2, 4097, 3, 0, 1)])
+def test_plain_c_host_peer_store_exchange(oracle, hip, ranks, envs, task, rollout, root):
+    """host/drone_host_mp --exchange peer: the same exchange from plain C (north-star: "host side stays C calling HIP
+    through a thin C-ABI") — fork before HIP, the root's export and the flag page through shared mappings made before the
+    fork, device memory through drone_device_malloc, no HIP or RCCL header in the host. The root copies every batch to
+    the host and chains a CRC-32 over it, which must equal ONE oracle run over all envs."""
+    steps, seed = 48, 31
+    cmd = [EXE_MP, "--gpus", str(ranks), "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed),
+           "--crc", "1", "--share-devices", "1", "--exchange", "peer", "--root", str(root), "--timeout", "120"]
+    if rollout:
+        cmd += ["--rollout", str(rollout)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    import json
+
+    got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert got["root"] == root and "peer-store" in got["mode"]
+    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=4)
+    o.reset(seed)
+    crc = zlib.crc32(o.observations.tobytes())
+    launches = steps if not rollout else (steps + rollout - 1) // rollout
+    for _ in range(launches):
+        if rollout:
+            o.rollout(rollout)
+        else:
+            o.fill_random_actions()
+            o.step()
+        for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+            crc = zlib.crc32(buf.tobytes(), crc)
+    assert got["crc32"] == crc, f"{ranks} ranks, root {root}: crc {got['crc32']:#x} != oracle {crc:#x}"
+
+
+def test_plain_c_host_peer_store_with_a_dead_rank_ends(hip):
+    """A rank SIGKILLed before the first launch: the parent reaps it, kills the rest and exits non-zero well inside the
+    time limit (the ranks blocked in the handshake are killed by the parent; their stream-side waits die with them)."""
+    r = subprocess.run([EXE_MP, "--gpus", "3", "--envs", "6000", "--steps", "10", "--share-devices", "1", "--exchange", "peer", "--die-rank", "1", "--timeout", "60"],
+                       capture_output=True, text=True, timeout=200, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode != 0 and "ended abnormally" in r.stderr, r.stderr[-1500:]

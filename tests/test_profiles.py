@@ -1,0 +1,77 @@
+"""profiles/r04_*: what is committed as evidence must be one consistent set (VERDICT r3 item 2b — half of profiles/r03_*
+named a kernel that no longer existed). Every round-4 profile directory names the build it measured (git revision, sha256
+of the libdrone_hip.so that ran on the GPU box) and its kernels by demangled and mangled name; here, on the CPU:
+  * the kernel rows of kernel_stats.csv and of summary.json are the same kernels;
+  * every mangled name exists in the ISA listing of the CURRENT sources (a kernel renamed or re-templated after the
+    profile was taken makes the profile stale: re-run tools/r04_profiles.sh + tools/collect_r04.py);
+  * all directories, traffic_latest.json and rollout_valu.json come from ONE build, taken from a clean tree;
+  * the roofline fraction of the committed bench line is reproduced from the profile: algorithmic bytes x envs /
+    rocprofv3's average kernel time / 8 TB/s."""
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r04_*")) if os.path.isfile(os.path.join(d, "summary.json")))
+
+pytestmark = pytest.mark.skipif(not DIRS, reason="no round-4 profiles committed yet")
+
+
+@pytest.fixture(scope="module")
+def isa_kernels():
+    src = os.path.join(ROOT, "drone_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", src, "asm"], check=True, capture_output=True)
+    return set(re.findall(r"^\s*\.amdhsa_kernel\s+(\S+)", open(os.path.join(src, "drone_kernels.s")).read(), re.M))
+
+
+def test_every_profile_names_its_kernels_consistently(isa_kernels):
+    for d in DIRS:
+        s = json.load(open(os.path.join(d, "summary.json")))
+        with open(os.path.join(d, "kernel_stats.csv")) as fh:
+            rows = list(csv.DictReader(fh))
+        assert [r["Name"] for r in rows] == [k["name"] for k in s["kernels"]], d
+        for r, k in zip(rows, s["kernels"]):
+            assert float(r["AverageNs"]) / 1e3 == pytest.approx(k["avg_us"]) and int(r["Calls"]) == k["calls"], (d, k["name"])
+            assert k["mangled"] in isa_kernels, f"{d}: {k['name']} is not a kernel of the current sources — stale profile"
+
+
+def test_one_build_behind_everything():
+    builds = {}
+    for d in DIRS:
+        b = json.load(open(os.path.join(d, "summary.json")))["build"]
+        builds[os.path.basename(d)] = (b["git_head"], b["so_sha256_on_the_gpu_box"])
+        assert b["so_sha256_on_the_gpu_box"] == b["so_sha256"], f"{d}: the library that ran is not the one build() produced"
+        assert b["git_dirty_files"] == [], f"{d}: profiled from a tree with uncommitted changes: {b['git_dirty_files']}"
+    assert len(set(builds.values())) == 1, builds
+    one = next(iter(builds.values()))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    for key, t in traffic.items():
+        assert (t["build"]["git_head"], t["build"]["so_sha256_on_the_gpu_box"]) == one, key
+    assert one[0][:12] in json.load(open(os.path.join(ROOT, "profiles", "rollout_valu.json")))["hover"]["source"]
+    sq = json.load(open(os.path.join(ROOT, "profiles", "r04_rollout_hover", "sq_counters.json")))
+    assert (sq["build"]["git_head"], sq["build"]["so_sha256_on_the_gpu_box"]) == one
+
+
+def test_the_bench_lines_roofline_is_reproduced_by_the_profile():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    rf = line["roofline"]
+    s = json.load(open(os.path.join(ROOT, "profiles", f"r04_step_hover_{rf['envs']}", "summary.json")))
+    k = next(x for x in s["kernels"] if "drone_step_kernel" in x["name"])
+    frac = rf["algorithmic_bytes_per_env_step"] * rf["envs"] / (k["avg_us"] * 1e-6) / 8e12
+    assert frac == pytest.approx(rf["frac"], rel=0.03), (frac, rf["frac"])
+    # ... and the metric's size beside it
+    am = rf["at_metric_size"]
+    s2 = json.load(open(os.path.join(ROOT, "profiles", "r04_step_hover", "summary.json")))
+    k2 = next(x for x in s2["kernels"] if "drone_step_kernel" in x["name"])
+    assert am["algorithmic_bytes_per_env_step"] * am["envs"] / (k2["avg_us"] * 1e-6) / 8e12 == pytest.approx(am["frac"], rel=0.03)
+    # the PMC traffic against the algorithmic bytes: no wasted re-reads
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[f"hover:{rf['envs']}"]
+    assert 0.97 < t["hbm_bytes_per_launch"] / (rf["algorithmic_bytes_per_env_step"] * rf["envs"]) < 1.05
+    # the variant strings in the line are the instantiations the profile saw
+    assert "stream=1,dt=1" in line["variants"][f"hover:{rf['envs']}"] and "<0, false, true, true>" in k["name"]  # task 0, no compaction, streamed action loads, derived-target layout
+    assert "stream=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, false, true>" in k2["name"]
