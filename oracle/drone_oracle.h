@@ -13,9 +13,17 @@
  *
  * Shape: one `Drone` struct per env with PufferLib-ocean-style entry points
  * init / c_reset / c_step over caller-owned obs / action / reward / terminal
- * buffers, one env at a time, array-of-structs, plain float — deliberately
- * the opposite of the device layout so that the two implementations share no
- * code and agreement between them means something.
+ * buffers, one env at a time, array-of-structs, plain float — the opposite of
+ * the device layout. What agreement with the HIP path does and does not show:
+ * the two share no code in the linker's sense, but they are ONE reading of
+ * SPEC.md typed twice by one author (compare c_step below with
+ * drone_amd/csrc/drone_lane.hpp): bit-exact agreement proves that the layouts,
+ * the kernels' plumbing (tiles, LDS transposes, ballots, resets in flight) and
+ * the gcc / hipcc numerics contracts agree — not that SPEC.md was read
+ * correctly. The second opinion on the READING is tests/spec_numpy.py, a
+ * float64 statement in a different evaluation order, checked on the CPU at
+ * <= 1e-5 (tests/test_oracle_independent.py); the pin that would settle it —
+ * upstream's C step() — is not in /root/reference.
  *
  * Build with -ffp-contract=off: the only fused operations are the fmaf()
  * calls written out below (SPEC.md preamble).
