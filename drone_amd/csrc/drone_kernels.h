@@ -54,10 +54,11 @@ hipError_t launch_fill_actions(const DeviceView& v, float* actions, uint32_t gst
 hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid, int* grid_out, hipStream_t s);
 
 // Peer-store exchange (drone_vec_gather_init_peer): the handshake on the stream. post: everything this stream has written
-// so far (the step kernel's stores into the root's HBM) is visible system-wide, then *flag = value. wait: one lane polls
-// *flag (a word in host memory shared by the ranks' processes) until it has reached `want`, sleeping between polls; gives
-// up after `budget_ticks` of the 100 MHz real-time counter and sets *err (host-mapped) instead of spinning for ever.
+// so far (the step kernel's stores into the root's HBM) is visible system-wide, then *flag = value. wait: lane r polls
+// flags[r] (words in host memory shared by the ranks' processes; r < count, r != skip) until it has reached `want`,
+// sleeping between polls; a lane gives up after `budget_ticks` of the 100 MHz real-time counter and sets *err
+// (host-mapped) instead of spinning for ever. ONE launch for all the ranks waited for.
 hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s);
-hipError_t launch_flag_wait(const uint32_t* flag, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s);
+hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s);
 
 }  // namespace drone

@@ -980,14 +980,18 @@ __global__ __launch_bounds__(64) void drone_flag_post_kernel(uint32_t* flag, uin
     }
 }
 
-__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flag, uint32_t want, uint32_t* err, unsigned long long budget_ticks) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-        __builtin_amdgcn_s_sleep(64);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
-            __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
+// One launch waits for ALL the flags it is given: lane r polls flag r (r < count, r != skip); the wave retires when every
+// lane has seen its flag reach `want` or has run out of budget.
+__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks) {
+    for (uint32_t r = threadIdx.x; r < count; r += 64u) {
+        if (r == skip) continue;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int32_t)(__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+            __builtin_amdgcn_s_sleep(64);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
+                __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
     }
 }
@@ -1105,9 +1109,9 @@ hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_flag_wait(const uint32_t* flag, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s) {
+hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s) {
     drop_stale_error();
-    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flag, want, err, budget_ticks);
+    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flags, count, skip, want, err, budget_ticks);
     return hipGetLastError();
 }
 

@@ -544,6 +544,7 @@ struct Gather {
     volatile uint32_t* flags = nullptr;  // the shared page: post[world] then ack
     char* d_flags = nullptr;             // its device address (hipStreamWriteValue32 / hipStreamWaitValue32)
     bool flags_registered = false;
+    bool stream_writes = false;          // DRONE_PEER_STREAM_WRITES=1: publish flags with hipStreamWriteValue32 instead of the one-wave kernel (measured SLOWER: see peer_post)
     bool gpu_waits = true;               // the handshake runs on the stream (two one-wave kernels); false (DRONE_PEER_HOST_WAIT=1): the host drains the stream and polls / stores
     uint32_t* h_err = nullptr;           // pinned + mapped word a stream-side wait sets when it gave up (a dead peer)
     uint32_t* d_err = nullptr;
@@ -584,26 +585,30 @@ void gather_destroy(DroneVec* v) {
 }
 
 // ---- peer-store exchange: the handshake ----
-// One value of the shared flag page reaches `want` (the counters only grow; compared as signed differences so that a
-// wrap after 2^32 rounds is harmless on the host path). On the stream where the hardware can wait for it
-// (hipStreamWaitValue32: the command processor polls the word, no host involvement); where it cannot, the host drains
-// the stream and polls, bounded by DRONE_PEER_TIMEOUT_MS (default 10 s) so that a dead peer is an error, not a hang.
+// Flags are words of a host-memory page shared by the ranks' processes; the counters only grow and are compared as signed
+// differences (a wrap after 2^32 rounds is harmless). Waiting: on the stream, ONE one-wave kernel whose lanes poll the
+// flags waited for (hipStreamWaitValue32 cannot: it takes only the calling process's signal memory), each lane giving up
+// after the time budget and raising the handle's error word; or, with DRONE_PEER_HOST_WAIT=1, on the host (drain the
+// stream, poll), where the same budget (DRONE_PEER_TIMEOUT_MS, default 10 s) makes a dead peer an immediate error.
 long peer_timeout_ms() {
     const char* t = getenv("DRONE_PEER_TIMEOUT_MS");
     return (t && *t) ? atol(t) : 10000;
 }
 
-bool peer_wait_ge(DroneVec* v, Gather* g, int slot, uint32_t want) {
-    if (g->gpu_waits) {  // one lane polls the shared word from the stream; gives up after the budget and says so in *d_err
-        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags + 4 * slot), want, g->d_err, g->budget_ticks, v->stream), return false);
+// flags [first, first + count) except `skip` (-1: none) have all reached `want`
+bool peer_wait_ge(DroneVec* v, Gather* g, int first, int count, int skip, uint32_t want) {
+    if (g->gpu_waits) {  // one launch, one lane per flag, polling the shared words from the stream; gives up after the budget and says so in *d_err
+        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags) + first, (uint32_t)count, (uint32_t)skip, want, g->d_err, g->budget_ticks, v->stream), return false);
         return true;
     }
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
     const long limit_ms = peer_timeout_ms();
     timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    int slot = first;
     for (uint32_t spins = 0;; spins++) {
-        if ((int32_t)(__atomic_load_n(g->flags + slot, __ATOMIC_ACQUIRE) - want) >= 0) return true;
+        while (slot < first + count && (slot - first == skip || (int32_t)(__atomic_load_n(g->flags + slot, __ATOMIC_ACQUIRE) - want) >= 0)) slot++;
+        if (slot == first + count) return true;
         if ((spins & 1023u) == 1023u) {
             clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) * 1000L + (t1.tv_nsec - t0.tv_nsec) / 1000000L > limit_ms) {
@@ -620,6 +625,15 @@ bool peer_wait_ge(DroneVec* v, Gather* g, int slot, uint32_t want) {
 // publish `value` in flag `slot` behind everything enqueued on the stream so far
 bool peer_post(DroneVec* v, Gather* g, int slot, uint32_t value) {
     if (g->gpu_waits) {
+        // A one-wave kernel (system-scope fence + store): one dependent launch boundary per flag — one rank stepping 2^20
+        // envs with the root's per-step acknowledgement takes 43.3 us per step against 40.4-40.7 without an exchange. The
+        // stream memory operation that looks cheaper (hipStreamWriteValue32: no kernel) is not: 46.1 us on the same box
+        // (profiles/r04_ab/peer_post_forms.txt). Kept behind DRONE_PEER_STREAM_WRITES=1.
+        if (g->stream_writes) {
+            if (hipStreamWriteValue32(v->stream, g->d_flags + 4 * slot, value, 0) == hipSuccess) return true;
+            (void)hipGetLastError();
+            g->stream_writes = false;
+        }
         HIP_TRY(launch_flag_post(reinterpret_cast<uint32_t*>(g->d_flags + 4 * slot), value, v->stream), return false);
         return true;
     }
@@ -652,7 +666,7 @@ bool peer_before_launch(DroneVec* v) {
         }
         return true;
     }
-    return peer_wait_ge(v, g, g->world, g->seq);
+    return peer_wait_ge(v, g, g->world, 1, -1, g->seq);
 }
 
 }  // namespace
@@ -1684,6 +1698,8 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
     if (!g->d_flags) { set_err("gather_init_peer: the flag page could not be mapped into the device address space"); gather_destroy(v); return -1; }
     const char* hw = getenv("DRONE_PEER_HOST_WAIT");
     if (hw && *hw && atoi(hw) != 0) g->gpu_waits = false;
+    const char* sw = getenv("DRONE_PEER_STREAM_WRITES");  // 1: publish flags with hipStreamWriteValue32 where the runtime takes the page
+    if (sw && *sw) g->stream_writes = atoi(sw) != 0;
     if (g->gpu_waits) {
         void* he = nullptr;
         HIP_TRY(hipHostMalloc(&he, 64, hipHostMallocMapped), { gather_destroy(v); return -1; });
@@ -1728,8 +1744,7 @@ int drone_vec_gather(DroneVec* v) {
         if (!peer_check_err(g)) return -1;
         g->seq += 1u;
         if (g->rank != g->root) return peer_post(v, g, g->rank, g->seq) ? 0 : -1;
-        for (int r = 0; r < g->world; r++)
-            if (r != g->root && !peer_wait_ge(v, g, r, g->seq)) return -1;
+        if (g->world > 1 && !peer_wait_ge(v, g, 0, g->world, g->root, g->seq)) return -1;
         return 0;
     }
     Rccl* R = rccl();

@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r04_prof")
-CXXFILT = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+CXXFILT = "c++filt"  # binutils; the ROCm image ships no llvm-cxxfilt
 
 
 def mangled_names():
