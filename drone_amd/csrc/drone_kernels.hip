@@ -461,16 +461,17 @@ __device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L,
 // steps 1-9 of one env step for any task (the swarm task looks at its neighbours in between).
 // CARRY: the state stays in registers from step to step and carries the rotor inputs (Lane::u) with it.
 // PK: the RK4 substep in packed f32 instructions (small shards; drone_pk.hpp).
-template <int TASK, bool CARRY = false, bool PK = false>
+// INRANGE: `act` was drawn by random_action in this kernel (values in [-1, 1): the clamp of SPEC.md section 5 step 1 is the identity).
+template <int TASK, bool CARRY = false, bool PK = false, bool INRANGE = false>
 __device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     if (TASK == DRONE_TASK_SWARM) {
         StepCtx ctx;
-        lane_integrate<TASK, CARRY, PK>(P, L, act, env, gstep, ctx);
+        lane_integrate<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, ctx);
         float nn_d2, nn_e[3];
         swarm_neighbour(P, L, tile, nn_d2, nn_e);
         lane_finish<TASK, CARRY>(P, L, env, ctx, nn_d2, out);
     } else {
-        lane_step<TASK, CARRY, PK>(P, L, act, env, gstep, out);
+        lane_step<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, out);
     }
 }
 
@@ -757,7 +758,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, true>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -830,7 +831,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     if (POLICY) random_action(P.key_action, env, gstep, act);
     else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
     StepOut out;
-    step_any<TASK, DRONE_CARRY_ROTOR != 0, PK>(P, L, tile, act, env, gstep, out);
+    step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, POLICY>(P, L, tile, act, env, gstep, out);
     const bool ended = out.oob || out.trunc;
     any_target |= out.target_changed;
     any_end |= ended;

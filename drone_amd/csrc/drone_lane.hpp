@@ -371,10 +371,14 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     // SPEC v5: (1, t) scaled to unit length by two Newton steps of 1/sqrt(n2) about 1 — 5 operations where the correctly
     // rounded sqrt + divide took 28 (two quarter-rate transcendentals among them) on the episode-end path
     const float n2 = fma_(t[0], t[0], fma_(t[1], t[1], fma_(t[2], t[2], 1.0f)));
+#if defined(DRONE_EXP_V4_EPISODE_END) && DRONE_EXP_V4_EPISODE_END  // MEASUREMENT ONLY (results differ from SPEC v5): the round-3 arithmetic, to price the change on one box
+    const float sc = 1.0f / sqrtf(n2);
+#else
     const float s1 = fma_(-0.5f, n2, 1.5f);
     const float m = (n2 * s1) * s1;
     const float s2 = fma_(-0.5f, m, 1.5f);
     const float sc = s1 * s2;
+#endif
     L.s.q[0] = sc;
     L.s.q[1] = t[0] * sc;
     L.s.q[2] = t[1] * sc;
@@ -415,12 +419,16 @@ struct StepCtx {
 };
 
 // SPEC.md §5 steps 1–4: actions, wind, RK4, renormalise, clamp, tick.
-template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT>
+// INRANGE: the caller drew `act` from the SPEC.md section 2 policy itself (random_action: s16 values, all in [-1, 1)), so the
+// clamp of step 1 is the identity and is left out — four instructions per step in the kernels that draw their own actions
+// (fused rollout, step_many with the in-kernel policy); bit-identical by construction, and pinned on the CPU by
+// tests/test_lane_host.py, whose rollout harness compiles this form against the oracle's (clamping) rollout.
+template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT, bool INRANGE = false>
 DRONE_FN void lane_integrate(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepCtx& ctx) {
     float a[4], cmd[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        a[i] = clampc(act[i], -1.0f, 1.0f);
+        a[i] = INRANGE ? act[i] : clampc(act[i], -1.0f, 1.0f);
         cmd[i] = P.half_max_rpm * (a[i] + 1.0f);
     }
     ctx.a2 = fma_(a[0], a[0], fma_(a[1], a[1], fma_(a[2], a[2], a[3] * a[3])));
@@ -543,7 +551,11 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
     out.perf = out.score = out.ep_return = out.ep_len = 0.0f;
     if (oob || trunc) {
         // SPEC v5: hover / swarm log the COUNT of steps within hover_radius (vec_log divides by the steps flown): no division here
+#if defined(DRONE_EXP_V4_EPISODE_END) && DRONE_EXP_V4_EPISODE_END
+        const float score = (TASK == DRONE_TASK_WAYPOINT || TASK == DRONE_TASK_RACE) ? (float)L.score_count : (float)L.score_count / (float)L.tick;
+#else
         const float score = (float)L.score_count;
+#endif
         float perf = score;
         if (TASK == DRONE_TASK_WAYPOINT || TASK == DRONE_TASK_RACE) perf = L.score_count >= 8u ? 1.0f : score * 0.125f;
         out.perf = perf;
@@ -558,10 +570,10 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
 }
 
 // Single-agent tasks: the whole of SPEC.md §5 steps 1–9.
-template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT>
+template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT, bool INRANGE = false>
 DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     StepCtx ctx;
-    lane_integrate<TASK, CARRY, PK>(P, L, act, env, gstep, ctx);
+    lane_integrate<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, ctx);
     lane_finish<TASK, CARRY>(P, L, env, ctx, 0.0f, out);
 }
 

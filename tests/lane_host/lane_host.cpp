@@ -135,8 +135,9 @@ static void rollout_task(const KParams& P, std::vector<Lane>& lanes, DroneStateR
             const uint32_t env = P.env_offset + (uint32_t)i;
             float act[4];
             random_action(P.key_action, env, gstep0 + (uint32_t)t, act);
-            if (TASK == DRONE_TASK_SWARM) lane_integrate<TASK, true>(P, lanes[i], act, env, gstep0 + (uint32_t)t, ctx[i]);
-            else lane_step<TASK, true>(P, lanes[i], act, env, gstep0 + (uint32_t)t, outs[i]);
+            // CARRY and INRANGE as the fused rollout kernel instantiates them (actions from random_action: no clamp)
+            if (TASK == DRONE_TASK_SWARM) lane_integrate<TASK, true, DRONE_PK_DEFAULT, true>(P, lanes[i], act, env, gstep0 + (uint32_t)t, ctx[i]);
+            else lane_step<TASK, true, DRONE_PK_DEFAULT, true>(P, lanes[i], act, env, gstep0 + (uint32_t)t, outs[i]);
         }
         if (TASK == DRONE_TASK_SWARM) {
             for (int i = 0; i < n; i++) {
