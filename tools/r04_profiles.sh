@@ -27,6 +27,9 @@ STEPS_ARGS="--steps 300 --warmup 30" bash tools/profile_gpu.sh $P/step_many_6553
 STEPS_ARGS="--steps 20 --warmup 30" bash tools/profile_gpu.sh $P/rollout_hover --mode rollout > /dev/null 2>&1
 bash tools/pmc_pass.sh $P/sq_rollout_hover "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" --mode rollout --steps 10 --warmup 2 > /dev/null 2>&1
 bash tools/pmc_pass.sh $P/sq_step_65536 "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU" --steps 200 --warmup 20 --envs-per-gpu 65536 > /dev/null 2>&1
+# collect on the box too, so that the bench lines below read THIS build's traffic_latest.json / rollout_valu.json
+# (the same collector runs again on the merged-back raw files at home and must produce the same profiles/)
+python3 tools/collect_r04.py > gpurun_out/$P/collect_on_box.log 2>&1
 python bench.py > gpurun_out/$P/bench_default.json 2> gpurun_out/$P/bench_default.err
 python bench.py --force-dist --steps 200 --warmup 20 > gpurun_out/$P/bench_force_dist_one_rank.json 2> gpurun_out/$P/bench_force_dist.err
 for d in step_hover_4194304 step_hover step_hover_65536 step_hover_131072 step_waypoint_262144 step_many_65536 rollout_hover; do echo "== $d"; python3 - "$d" <<'PY'
