@@ -45,6 +45,8 @@ def draw_case(rng, big=False):
         n = max(agents, n // agents * agents)
         over["agents_per_env"] = agents
     over["env_offset"] = int(rng.integers(0, 1 << 20)) // agents * agents
+    if rng.random() < 0.4:  # round 4: the state layout as a declared choice (DroneConfig.state_layout); derived target only where it can hold the handle
+        over["state_layout"] = int(rng.choice([abi.LAYOUT_TARGET_PLANE, abi.LAYOUT_DERIVED_TARGET] if task in (abi.TASK_HOVER, abi.TASK_SWARM) else [abi.LAYOUT_TARGET_PLANE]))
     if rng.random() < 0.5:  # scale a few physics / task constants; every kernel reads them from the same KParams
         for name in rng.choice(SCALED, size=int(rng.integers(1, 6)), replace=False):
             over[str(name)] = ("scale", float(rng.uniform(0.5, 2.0)))
