@@ -50,6 +50,9 @@
 #ifndef DRONE_NT_STATE_STORES  // 1: non-temporal stores for the state planes too (plain: +0.4 % at 2^20, +4 % at 131 072, 0 at 2^22)
 #define DRONE_NT_STATE_STORES 1
 #endif
+#ifndef DRONE_NT_STATE_LOADS  // 1: non-temporal loads of the state planes in the per-step kernel (experiment, round 4: do the planes stay in the Infinity Cache if only their STORES allocate?)
+#define DRONE_NT_STATE_LOADS 0
+#endif
 #ifndef DRONE_NT_ACTION_LOADS  // 1: force non-temporal action loads at every size (default: only the instantiation the host picks for HBM-only footprints)
 #define DRONE_NT_ACTION_LOADS 0
 #endif
@@ -196,13 +199,23 @@ struct RawLane {
 // DT: the derived-target layout (drone_params.hpp): five planes per tile, no target plane to read.
 template <int TASK, bool STREAM, bool DT>
 __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawLane<TASK>& R) {
-    R.a = pl[hot_index(hot_planes(TASK, DT), kP0, i, np)];
-    R.b = pl[hot_index(hot_planes(TASK, DT), kP1, i, np)];
-    R.c = pl[hot_index(hot_planes(TASK, DT), kP2, i, np)];
-    R.d = pl[hot_index(hot_planes(TASK, DT), kP3, i, np)];
-    R.e = pl[hot_index(hot_planes(TASK, DT), kP4, i, np)];
-    if (!DT) R.t = pl[hot_index(hot_planes(TASK, DT), kPT, i, np)];
-    if (has_aux_plane<TASK>()) R.w = pl[hot_index(hot_planes(TASK, DT), kPW, i, np)];
+#if DRONE_NT_STATE_LOADS
+#define DRONE_PLANE_LOAD(dst, plane)                                                                                     \
+    do {                                                                                                                 \
+        const f4_t x_ = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(pl) + hot_index(hot_planes(TASK, DT), plane, i, np)); \
+        dst = make_float4(x_.x, x_.y, x_.z, x_.w);                                                                       \
+    } while (0)
+#else
+#define DRONE_PLANE_LOAD(dst, plane) dst = pl[hot_index(hot_planes(TASK, DT), plane, i, np)]
+#endif
+    DRONE_PLANE_LOAD(R.a, kP0);
+    DRONE_PLANE_LOAD(R.b, kP1);
+    DRONE_PLANE_LOAD(R.c, kP2);
+    DRONE_PLANE_LOAD(R.d, kP3);
+    DRONE_PLANE_LOAD(R.e, kP4);
+    if (!DT) DRONE_PLANE_LOAD(R.t, kPT);
+    if (has_aux_plane<TASK>()) DRONE_PLANE_LOAD(R.w, kPW);
+#undef DRONE_PLANE_LOAD
     // Non-temporal only where nothing is cached anyway (STREAM: the host picks that instantiation by footprint: -2 % at
     // 2^22 envs, but +19 % at 2^20 and +7 % at 131 072, where the hint pushes the rows out of the caches that serve them).
     if (STREAM) {  // compile time: a run-time branch here would make the wait-count pass drain all loads at the join
