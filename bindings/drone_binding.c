@@ -687,6 +687,15 @@ static PyObject* vec_host_pin(PyObject* self, PyObject* args) { (void)self; retu
 static PyObject* vec_host_unpin(PyObject* self, PyObject* args) { (void)self; return host_pin_impl(args, 0); }
 
 /* vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers */
+static PyObject* vec_variant(PyObject* self, PyObject* args) {
+    (void)self;
+    PyObject* cap;
+    if (!PyArg_ParseTuple(args, "O", &cap)) return NULL;
+    Handle* h = get_handle(cap);
+    if (!h) return NULL;
+    return PyUnicode_FromString(drone_vec_variant(h->v));
+}
+
 static PyObject* vec_host_transport(PyObject* self, PyObject* args) {
     (void)self;
     PyObject* cap;
@@ -739,6 +748,7 @@ static PyMethodDef methods[] = {
     {"vec_device", vec_device, METH_VARARGS, "vec_device(handle) -> HIP device ordinal the env lives on"},
     {"vec_host_pin", vec_host_pin, METH_VARARGS, "vec_host_pin(handle, buffer, pages_exclusive=0): pin a page-owning host block for in-place access by vec_step_many"},
     {"vec_host_unpin", vec_host_unpin, METH_VARARGS, "vec_host_unpin(handle, buffer)"},
+    {"vec_variant", vec_variant, METH_VARARGS, "vec_variant(handle) -> which per-step kernel instantiation and launch choices the env uses, as text (drone_vec_variant)"},
     {"vec_host_transport", vec_host_transport, METH_VARARGS, "vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers"},
     {"vec_sync", vec_sync, METH_VARARGS, "vec_sync(handle): wait until everything enqueued on the env's stream has finished"},
     {"obs_dim", obs_dim, METH_VARARGS, "obs_dim(task) -> floats per observation row"},

@@ -1716,10 +1716,19 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
         glob[2] = reinterpret_cast<char*>(v->px_term); glob[3] = reinterpret_cast<char*>(v->px_trunc);
     } else {
         PeerBuf in4[4];
+        void* opened[4] = {nullptr, nullptr, nullptr, nullptr};
         memcpy(in4, token, sizeof(in4));
         for (int k = 0; k < 4; k++) {
-            HIP_TRY(hipIpcOpenMemHandle(&g->peer_base[k], in4[k].handle, hipIpcMemLazyEnablePeerAccess), { gather_destroy(v); return -1; });
-            glob[k] = static_cast<char*>(g->peer_base[k]) + in4[k].offset;
+            // several of the four buffers may live in ONE allocation (a caching allocator's segment): map each allocation once
+            void* base = nullptr;
+            for (int j = 0; j < k && !base; j++)
+                if (memcmp(&in4[j].handle, &in4[k].handle, sizeof(hipIpcMemHandle_t)) == 0) base = opened[j];
+            if (!base) {
+                HIP_TRY(hipIpcOpenMemHandle(&base, in4[k].handle, hipIpcMemLazyEnablePeerAccess), { gather_destroy(v); return -1; });
+                g->peer_base[k] = base;  // closed by gather_destroy
+            }
+            opened[k] = base;
+            glob[k] = static_cast<char*>(base) + in4[k].offset;
         }
     }
     g->g_obs = reinterpret_cast<float*>(glob[0]); g->g_rew = reinterpret_cast<float*>(glob[1]);

@@ -31,7 +31,7 @@ def host_buffers(n, task):
 
 def test_module_surface_and_argument_checks(ext):
     for name in ("vec_init", "vec_reset", "vec_step", "vec_log", "vec_close", "vec_rollout", "vec_set_stream", "vec_fill_random_actions", "vec_gstep",
-                 "vec_send", "vec_recv", "vec_step_many", "vec_step_repeat", "vec_done_list_at", "vec_dlpack", "vec_device", "vec_sync", "vec_host_transport", "vec_host_pin", "vec_host_unpin"):
+                 "vec_send", "vec_recv", "vec_step_many", "vec_step_repeat", "vec_done_list_at", "vec_dlpack", "vec_device", "vec_sync", "vec_host_transport", "vec_host_pin", "vec_host_unpin", "vec_variant"):
         assert callable(getattr(ext, name))
     assert ext.obs_dim(0) == 20 and ext.obs_dim(3) == 24 and ext.TASK_SWARM == 2
     b = host_buffers(16, 0)
@@ -121,7 +121,16 @@ def test_binding_device_tensors_and_rollout(ext, oracle):
     assert_bits_equal(o.truncations, trunc, "rollout truncations")
     with pytest.raises(RuntimeError, match="horizon must be positive"):
         ext.vec_rollout(h, 0)
+    assert ext.vec_variant(h).startswith("drone_step_kernel<task=1,compact=0,stream=0,dt=0>") and "bytes=310" in ext.vec_variant(h)
     del h  # capsule destructor closes the env
+    # round 4: the state layout as an env kwarg (DroneConfig.state_layout) reaches the library through the kwargs table
+    o2 = [torch.zeros((512, 20), dtype=torch.float32, device=dev), torch.zeros((512, 4), dtype=torch.float32, device=dev), torch.zeros(512, dtype=torch.float32, device=dev),
+          torch.zeros(512, dtype=torch.uint8, device=dev), torch.zeros(512, dtype=torch.uint8, device=dev)]
+    h2 = ext.vec_init(*o2, 512, seed, task=0, state_layout=2)
+    assert "dt=1" in ext.vec_variant(h2) and "bytes=262" in ext.vec_variant(h2)
+    del h2
+    with pytest.raises(RuntimeError, match="state_layout"):
+        ext.vec_init(*o2, 512, seed, task=1, state_layout=2)
 
 
 def test_buffer_format_and_size_checks(ext):
