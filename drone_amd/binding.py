@@ -338,7 +338,7 @@ class DroneVec:
     @property
     def variant(self):
         """Which per-step kernel instantiation and launch choices this handle uses (``drone_vec_variant``), as text and
-        parsed: {'task': 0, 'compact': 0, 'stream': 0, 'dt': 1, 'order': 1, 'line_complete': 0, 'packed_rk4': 0, 'bytes': 262}."""
+        parsed: {'task': 0, 'compact': 0, 'mem': 0, 'dt': 1, 'order': 1, 'line_complete': 0, 'packed_rk4': 0, 'bytes': 262}."""
         import re
 
         text = self._f["drone_vec_variant"](self._h).decode()

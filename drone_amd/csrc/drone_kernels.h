@@ -16,7 +16,7 @@ struct DeviceView {
     uint32_t n;          // envs on this device
     uint32_t n_pad;      // n rounded up to a whole workgroup: lanes [n, n_pad) exist and hold a valid reset state
     uint32_t stride;     // float4 elements between the two cold planes (>= n_pad)
-    uint32_t order;      // sweep order of the step kernel's workgroups: bit 0 one contiguous eighth per XCD, bit 1 reverse on odd steps, bit 2 non-temporal action loads (drone_kernels.hip my_chunk)
+    uint32_t order;      // per-step kernel, chosen from the bytes one step touches: bit 0 one contiguous eighth of the envs per XCD, bit 1 reverse the sweep on odd steps (drone_kernels.hip my_chunk); bit 2 non-temporal action loads, bit 3 non-temporal state loads (load_raw's MEM)
     uint32_t line_complete; // 1: rare per-lane plane updates go out as whole 128-B lines (working set beyond the Infinity Cache)
     uint32_t derived_target; // 1: derived-target layout (hover / swarm): five planes per tile, no target plane, episode in P4 (drone_params.hpp)
     uint32_t packed_rk4; // 1: the fused rollout / step_many kernels run the RK4 substep in packed f32 instructions (small shards: one wave per SIMD)

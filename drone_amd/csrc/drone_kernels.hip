@@ -197,28 +197,30 @@ struct RawLane {
 // make the consumer of the CURRENT chunk wait for the prefetched one too. `ia` is the action row to read, already
 // clamped into the buffer by the caller (lanes >= n read the last row and never store anything).
 // DT: the derived-target layout (drone_params.hpp): five planes per tile, no target plane to read.
-template <int TASK, bool STREAM, bool DT>
+// MEM: which of the loads carry the non-temporal hint — bit 0 the action rows, bit 1 the state planes. A compile-time choice
+// (a run-time branch here would make the wait-count pass drain all loads at the join), made by the host per handle from the
+// bytes one step touches (DeviceView::order bits 2 and 3): a hint is worth something only where the line would not have
+// been served from a cache anyway, and costs dearly where it would (state planes: +21 % at 2^20 envs, -10 % at 2^21;
+// action rows: +19 % at 2^20, -2 % at 2^23 — profiles/r04_ab/band_*.txt, r02_ab/ab_o6_*.txt).
+template <int TASK, int MEM, bool DT>
 __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawLane<TASK>& R) {
-#if DRONE_NT_STATE_LOADS
-#define DRONE_PLANE_LOAD(dst, plane)                                                                                     \
-    do {                                                                                                                 \
-        const f4_t x_ = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(pl) + hot_index(hot_planes(TASK, DT), plane, i, np)); \
-        dst = make_float4(x_.x, x_.y, x_.z, x_.w);                                                                       \
-    } while (0)
-#else
-#define DRONE_PLANE_LOAD(dst, plane) dst = pl[hot_index(hot_planes(TASK, DT), plane, i, np)]
-#endif
-    DRONE_PLANE_LOAD(R.a, kP0);
-    DRONE_PLANE_LOAD(R.b, kP1);
-    DRONE_PLANE_LOAD(R.c, kP2);
-    DRONE_PLANE_LOAD(R.d, kP3);
-    DRONE_PLANE_LOAD(R.e, kP4);
-    if (!DT) DRONE_PLANE_LOAD(R.t, kPT);
-    if (has_aux_plane<TASK>()) DRONE_PLANE_LOAD(R.w, kPW);
-#undef DRONE_PLANE_LOAD
-    // Non-temporal only where nothing is cached anyway (STREAM: the host picks that instantiation by footprint: -2 % at
-    // 2^22 envs, but +19 % at 2^20 and +7 % at 131 072, where the hint pushes the rows out of the caches that serve them).
-    if (STREAM) {  // compile time: a run-time branch here would make the wait-count pass drain all loads at the join
+    constexpr bool NT_STATE = (MEM & 2) != 0 || DRONE_NT_STATE_LOADS, NT_ACT = (MEM & 1) != 0 || DRONE_NT_ACTION_LOADS;
+    auto plane = [&](int p) {
+        const uint32_t e = hot_index(hot_planes(TASK, DT), p, i, np);
+        if (NT_STATE) {
+            const f4_t x = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(pl) + e);
+            return make_float4(x.x, x.y, x.z, x.w);
+        }
+        return pl[e];
+    };
+    R.a = plane(kP0);
+    R.b = plane(kP1);
+    R.c = plane(kP2);
+    R.d = plane(kP3);
+    R.e = plane(kP4);
+    if (!DT) R.t = plane(kPT);
+    if (has_aux_plane<TASK>()) R.w = plane(kPW);
+    if (NT_ACT) {
         const f4_t av = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(actions) + ia);
         R.act = make_float4(av.x, av.y, av.z, av.w);
     } else {
@@ -528,7 +530,7 @@ __device__ __forceinline__ void advance_counters(const StepArgs& a, const Counte
 
 // which 256-drone chunk this workgroup owns. `order` (a launch argument, chosen by the host from the step's
 // footprint; DeviceView::order) — bit 0: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the
-// envs instead of being dealt round-robin over one global sweep; bit 2: non-temporal action loads (load_raw);
+// envs instead of being dealt round-robin over one global sweep; bits 2 and 3: non-temporal action / state loads (load_raw);
 // bit 1 (odd steps only): sweep in reverse, so the
 // lines touched last in one step are the first touched in the next and are still in the Infinity Cache.
 // Bijective for any grid size; a speed choice only (profiles/r02_ab/ab_zz_*.txt, ab_order_*.txt).
@@ -565,7 +567,7 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uin
 #define DRONE_STEP_PRE_PARAMS const float4* __restrict__ pre_planes, const float* __restrict__ pre_act, const uint32_t* __restrict__ pre_ctr, uint32_t pre_n, uint32_t pre_n_pad, \
                               uint32_t pre_order, uint32_t pre_nwg, uint32_t pre_gstep, uint32_t pre_slot
 
-template <int TASK, bool COMPACT, bool STREAM, bool DT>
+template <int TASK, bool COMPACT, int MEM, bool DT>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -599,7 +601,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
 #endif
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
-    load_raw<TASK, STREAM, DT>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
+    load_raw<TASK, MEM, DT>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
 #if DRONE_EARLY_ARGS == 2
     // everything above came out of preloaded SGPRs: the state loads are in flight before the kernel's first scalar-memory
     // wait. Nothing may be scheduled across this point (a hoisted s_load + s_waitcnt, or a load sunk below one).
@@ -614,7 +616,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
         const bool more = t + 1 < DRONE_STEP_TILES && block_base + kBlock < n_pad;  // workgroup-uniform
         if (t + 1 < DRONE_STEP_TILES) {  // compile-time: the next chunk's loads are in flight while this one computes
             const uint32_t j = min(i + kBlock, n_pad - kBlock + threadIdx.x);  // past the end: this chunk again (unused)
-            load_raw<TASK, STREAM, DT>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
+            load_raw<TASK, MEM, DT>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
         }
 
         Lane L;
@@ -1052,19 +1054,23 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
     a.nwg = g.x;
     const bool compact = v.done_ids != nullptr;
-    const bool stream = (v.order & 4u) != 0 || DRONE_NT_ACTION_LOADS;  // non-temporal action loads: HBM-only footprints
+    const int mem = (int)((v.order >> 2) & 3u);  // bit 0: non-temporal action loads, bit 1: non-temporal state loads (DeviceView::order bits 2, 3)
 #define DRONE_PRE_ARGS a.v.planes, a.v.act, a.v.ctr, a.v.n, a.v.n_pad, a.v.order, a.nwg, a.gstep, a.done_slot
-#define DRONE_LAUNCH_STEP2(T, D)                                                             \
+#define DRONE_LAUNCH_STEP3(T, C, D)                                                          \
     do {                                                                                     \
-        if (compact) { if (stream) drone_step_kernel<T, true, true, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); else drone_step_kernel<T, true, false, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); } \
-        else { if (stream) drone_step_kernel<T, false, true, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); else drone_step_kernel<T, false, false, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); }    \
+        if (mem == 0) drone_step_kernel<T, C, 0, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a);      \
+        else if (mem == 1) drone_step_kernel<T, C, 1, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); \
+        else if (mem == 2) drone_step_kernel<T, C, 2, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); \
+        else drone_step_kernel<T, C, 3, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a);               \
     } while (0)
+#define DRONE_LAUNCH_STEP2(T, D) do { if (compact) DRONE_LAUNCH_STEP3(T, true, D); else DRONE_LAUNCH_STEP3(T, false, D); } while (0)
 #define DRONE_LAUNCH_STEP(T) DRONE_LAUNCH_STEP2(T, false)
     const bool dt = v.derived_target != 0;
     if (task == DRONE_TASK_HOVER) { if (dt) DRONE_LAUNCH_STEP2(DRONE_TASK_HOVER, true); else DRONE_LAUNCH_STEP(DRONE_TASK_HOVER); }
     else if (task == DRONE_TASK_SWARM) { if (dt) DRONE_LAUNCH_STEP2(DRONE_TASK_SWARM, true); else DRONE_LAUNCH_STEP(DRONE_TASK_SWARM); }
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_STEP(DRONE_TASK_RACE);
     else DRONE_LAUNCH_STEP(DRONE_TASK_WAYPOINT);
+#undef DRONE_LAUNCH_STEP3
 #undef DRONE_LAUNCH_STEP2
 #undef DRONE_LAUNCH_STEP
 #undef DRONE_PRE_ARGS

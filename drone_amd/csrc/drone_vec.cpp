@@ -948,8 +948,19 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // Infinity Cache, one contiguous eighth per XCD (-2.7 % at 2^20 envs); beyond, one global round-robin sweep
         // (-6 % at 2^21) that turns around on odd steps once a step dwarfs the cache (-6 % at 2^22: the tail of one
         // step is the head of the next and is still cached), with the action rows streamed (bit 2: -2 % there).
+        // Round 4, hover task in the derived-target layout (where the band was swept end to end, profiles/r04_ab/band_*.txt,
+        // upper_*.txt): between ~400 MiB and ~1.1 GiB touched per step — a step that is one to four times the Infinity
+        // Cache, the LRU worst case — the STATE loads carry the non-temporal hint (bit 3) on a plain round-robin sweep:
+        // -3 % at 426 MiB, -10 ... -11.5 % from 458 to 655 MiB (2^21 envs: 97.6 -> 87.9 us), -10 % at 786 MiB (where the
+        // old rule's reversed sweep was 12 % behind a plain one), -6 % at 917 MiB, -1.8 % at 2^22 envs; beyond ~1.1 GiB the
+        // reversed sweep with streamed action rows wins again (+2 ... +4 % for the hint from 4.5 M envs on). The hint costs
+        // +21 % at 2^20 envs, hence a band and not a switch; and it is the hover task's band only: the seven-plane tasks
+        // lose 4 % to it at the same footprints (waypoint 1.75 M envs, race 2 M), the swarm task prefers order 6 there.
         const char* o = getenv("DRONE_SWEEP_ORDER");
-        v->dv.order = (o && *o) ? (uint32_t)atoi(o) : (touched <= ((size_t)400 << 20) ? 1u : touched <= ((size_t)768 << 20) ? 0u : 6u);
+        const bool hover_dt = cfg->task == DRONE_TASK_HOVER && dt;
+        uint32_t order = touched <= ((size_t)400 << 20) ? 1u : touched <= ((size_t)768 << 20) ? 0u : 6u;
+        if (hover_dt && touched > ((size_t)400 << 20) && touched <= ((size_t)1100 << 20)) order = 8u;
+        v->dv.order = (o && *o) ? (uint32_t)atoi(o) : order;
     }
     {   // Packed-f32 RK4 in the register-resident kernels (fused rollout, step_many): wins only while a SIMD holds ONE
         // wave (<= 65 536 envs on the 1024 SIMDs: rollout -8.8 %, step_many -3.9 %; waypoint / race -3...4 %), where the
@@ -962,8 +973,8 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
-    snprintf(v->variant, sizeof(v->variant), "drone_step_kernel<task=%d,compact=%d,stream=%d,dt=%d> order=%u line_complete=%u packed_rk4=%u bytes=%d",
-             cfg->task, v->dv.done_ids ? 1 : 0, (v->dv.order & 4u) ? 1 : 0, v->dv.derived_target ? 1 : 0, v->dv.order, v->dv.line_complete,
+    snprintf(v->variant, sizeof(v->variant), "drone_step_kernel<task=%d,compact=%d,mem=%u,dt=%d> order=%u line_complete=%u packed_rk4=%u bytes=%d",
+             cfg->task, v->dv.done_ids ? 1 : 0, (v->dv.order >> 2) & 3u, v->dv.derived_target ? 1 : 0, v->dv.order, v->dv.line_complete,
              v->dv.packed_rk4, drone_vec_bytes_per_env_step(v));
 #undef INIT_TRY
     if (debug_reg()) fprintf(stderr, "[drone reg] init %p n=%d %s%s obs=%p act=%p planes=%p\n", (void*)v, v->n, v->host_buffers ? "host" : "device", v->zero_copy ? " zero-copy" : "", (void*)observations, (void*)actions, (void*)v->dv.planes);

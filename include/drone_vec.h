@@ -118,11 +118,12 @@ int drone_device_count(void);
 int drone_vec_bytes_per_env_step(const DroneVec* v);
 
 /* Which instantiation of the per-step kernel this handle launches and the per-handle launch choices, as text:
- * "drone_step_kernel<task=0,compact=0,stream=0,dt=1> order=1 line_complete=0 packed_rk4=0 bytes=262" — task, done-id
- * compaction, non-temporal action loads, derived-target layout (the four template arguments of drone_step_kernel), the
- * sweep order, whole-line widening of rare plane updates, packed-f32 RK4 in the register-resident kernels, and the
- * algorithmic bytes per env-step. Tests use it to assert that the sizes bench.py times run the instantiations the
- * parity suite covers (tests/test_configs_gpu.py). The string lives in the handle. */
+ * "drone_step_kernel<task=0,compact=0,mem=0,dt=1> order=1 line_complete=0 packed_rk4=0 bytes=262" — task, done-id
+ * compaction, which loads carry the non-temporal hint (bit 0 the action rows, bit 1 the state planes), derived-target
+ * layout (the four template arguments of drone_step_kernel), the sweep order word (DeviceView::order), whole-line
+ * widening of rare plane updates, packed-f32 RK4 in the register-resident kernels, and the algorithmic bytes per
+ * env-step. Tests use it to assert that the sizes bench.py times run the instantiations the parity suite covers
+ * (tests/test_configs_gpu.py). The string lives in the handle. */
 const char* drone_vec_variant(const DroneVec* v);
 
 /* How host-buffer steps of this handle move their data: 1 = zero-copy (the kernel reads / writes the caller's pinned

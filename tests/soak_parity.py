@@ -51,7 +51,7 @@ def draw_case(rng, big=False):
         for name in rng.choice(SCALED, size=int(rng.integers(1, 6)), replace=False):
             over[str(name)] = ("scale", float(rng.uniform(0.5, 2.0)))
     env = {"DRONE_DERIVED_TARGET": rng.choice(["", "0", "1"]), "DRONE_PACKED_RK4": rng.choice(["", "0", "1"]),
-           "DRONE_LINE_COMPLETE": rng.choice(["", "0", "1"]), "DRONE_SWEEP_ORDER": rng.choice(["", "0", "1", "6"]),
+           "DRONE_LINE_COMPLETE": rng.choice(["", "0", "1"]), "DRONE_SWEEP_ORDER": rng.choice(["", "0", "1", "6", "8", "15"]),
            "DRONE_HOST_ZEROCOPY": rng.choice(["", "0", "1"])}
     return {"task": task, "n": n, "seed": int(rng.integers(0, 1 << 62)), "device": bool(rng.integers(0, 2)), "over": over, "env": env,
             "graph_safe": bool(rng.random() < 0.25), "ops": int(rng.integers(3, 7) if big else rng.integers(4, 14)), "max_k": 3 if big else 9,

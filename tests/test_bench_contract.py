@@ -45,7 +45,7 @@ def test_bench_line_has_the_contract_fields(hip):
     assert am["achieved"] * 1e9 == pytest.approx(d["value"] * am["algorithmic_bytes_per_env_step"], rel=0.3)
     # which kernel instantiation every timed handle ran
     assert set(d["variants"]) >= {"hover:65536", "hover:4194304", "hover:1024", "hover:131072", "waypoint:262144"}
-    assert "dt=1" in d["variants"]["hover:4194304"] and "order=6" in d["variants"]["hover:4194304"] and "dt=0" in d["variants"]["hover:65536"]
+    assert "mem=2,dt=1" in d["variants"]["hover:4194304"] and "order=8" in d["variants"]["hover:4194304"] and "dt=0" in d["variants"]["hover:65536"]
     # round 3: every other single-GPU BASELINE workload timed in the same run, each with its own bytes
     cf = d["configs"]
     assert set(cf) == {"configs[0]", "configs[1]", "configs[2]/shard", "configs[3]"}

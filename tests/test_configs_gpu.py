@@ -182,13 +182,13 @@ import bench  # noqa: E402  (module level of bench.py imports nothing heavy)
 TASK_IDS = {"hover": 0, "waypoint": 1, "swarm": 2, "race": 3}
 # what the library is expected to pick for the sizes the headline rests on; a changed heuristic must be noticed here
 EXPECTED_VARIANT = {
-    ("hover", 1 << 20): dict(task=0, compact=0, stream=0, dt=1, order=1, line_complete=0, packed_rk4=0, bytes=262),
-    ("hover", 1 << 22): dict(task=0, compact=0, stream=1, dt=1, order=6, line_complete=1, packed_rk4=0, bytes=262),
-    ("hover", 1 << 23): dict(task=0, compact=0, stream=1, dt=1, order=6, line_complete=1, packed_rk4=0, bytes=262),
-    ("hover", 65536): dict(task=0, compact=0, stream=0, dt=0, order=1, line_complete=0, packed_rk4=1, bytes=278),
-    ("hover", 131072): dict(task=0, compact=0, stream=0, dt=0, order=1, line_complete=0, packed_rk4=0, bytes=278),
-    ("hover", 1 << 19): dict(task=0, compact=0, stream=0, dt=1, order=1, line_complete=0, packed_rk4=0, bytes=262),
-    ("waypoint", 262144): dict(task=1, compact=0, stream=0, dt=0, order=1, line_complete=0, packed_rk4=0, bytes=310),
+    ("hover", 1 << 20): dict(task=0, compact=0, mem=0, dt=1, order=1, line_complete=0, packed_rk4=0, bytes=262),
+    ("hover", 1 << 22): dict(task=0, compact=0, mem=2, dt=1, order=8, line_complete=1, packed_rk4=0, bytes=262),   # non-temporal STATE loads, plain sweep
+    ("hover", 1 << 23): dict(task=0, compact=0, mem=1, dt=1, order=6, line_complete=1, packed_rk4=0, bytes=262),   # reversed sweep, streamed action rows
+    ("hover", 65536): dict(task=0, compact=0, mem=0, dt=0, order=1, line_complete=0, packed_rk4=1, bytes=278),
+    ("hover", 131072): dict(task=0, compact=0, mem=0, dt=0, order=1, line_complete=0, packed_rk4=0, bytes=278),
+    ("hover", 1 << 19): dict(task=0, compact=0, mem=0, dt=1, order=1, line_complete=0, packed_rk4=0, bytes=262),
+    ("waypoint", 262144): dict(task=1, compact=0, mem=0, dt=0, order=1, line_complete=0, packed_rk4=0, bytes=310),
 }
 
 

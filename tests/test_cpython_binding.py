@@ -121,7 +121,7 @@ def test_binding_device_tensors_and_rollout(ext, oracle):
     assert_bits_equal(o.truncations, trunc, "rollout truncations")
     with pytest.raises(RuntimeError, match="horizon must be positive"):
         ext.vec_rollout(h, 0)
-    assert ext.vec_variant(h).startswith("drone_step_kernel<task=1,compact=0,stream=0,dt=0>") and "bytes=310" in ext.vec_variant(h)
+    assert ext.vec_variant(h).startswith("drone_step_kernel<task=1,compact=0,mem=0,dt=0>") and "bytes=310" in ext.vec_variant(h)
     del h  # capsule destructor closes the env
     # round 4: the state layout as an env kwarg (DroneConfig.state_layout) reaches the library through the kwargs table
     o2 = [torch.zeros((512, 20), dtype=torch.float32, device=dev), torch.zeros((512, 4), dtype=torch.float32, device=dev), torch.zeros(512, dtype=torch.float32, device=dev),

@@ -73,5 +73,5 @@ def test_the_bench_lines_roofline_is_reproduced_by_the_profile():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[f"hover:{rf['envs']}"]
     assert 0.97 < t["hbm_bytes_per_launch"] / (rf["algorithmic_bytes_per_env_step"] * rf["envs"]) < 1.05
     # the variant strings in the line are the instantiations the profile saw
-    assert "stream=1,dt=1" in line["variants"][f"hover:{rf['envs']}"] and "<0, false, true, true>" in k["name"]  # task 0, no compaction, streamed action loads, derived-target layout
-    assert "stream=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, false, true>" in k2["name"]
+    assert "mem=2,dt=1" in line["variants"][f"hover:{rf['envs']}"] and "<0, false, 2, true>" in k["name"]  # task 0, no compaction, non-temporal state loads, derived-target layout
+    assert "mem=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, 0, true>" in k2["name"]

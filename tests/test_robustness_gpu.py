@@ -204,7 +204,7 @@ def test_c_abi_gather_host_buffers_ragged_counts(oracle, hip, monkeypatch):
     h.gather_close()
 
 
-@pytest.mark.parametrize("order", ["0", "1", "2", "3", "6", "7"])
+@pytest.mark.parametrize("order", ["0", "1", "2", "3", "6", "7", "8", "11", "14"])  # bits 2 / 3: non-temporal action / state loads (other instantiations of the kernel)
 @pytest.mark.parametrize("n", [5000, 70001])
 def test_sweep_orders_are_bijective(oracle, hip, monkeypatch, order, n):
     """DRONE_SWEEP_ORDER only permutes which workgroup takes which 256-drone chunk (round-robin / one eighth per XCD,
