@@ -944,10 +944,10 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         const char* e = getenv("DRONE_LINE_COMPLETE");
         const size_t touched = n * (sizeof(float4) * (dt ? 2 * hot_planes(cfg->task, true) : 2 * hot_planes(cfg->task) - 1) + (size_t)drone_obs_dim(cfg->task) * 4 + 16 + 6);
         v->dv.line_complete = (e && *e) ? (atoi(e) != 0) : (touched > ((size_t)512 << 20));
-        // Sweep order of the step kernel, by the same footprint (DRONE_SWEEP_ORDER=0..7 forces it): up to ~1.5x the
+        // Sweep order of the step kernel, by the same footprint (DRONE_SWEEP_ORDER=0..15 forces it): up to ~1.5x the
         // Infinity Cache, one contiguous eighth per XCD (-2.7 % at 2^20 envs); beyond, one global round-robin sweep
-        // (-6 % at 2^21) that turns around on odd steps once a step dwarfs the cache (-6 % at 2^22: the tail of one
-        // step is the head of the next and is still cached), with the action rows streamed (bit 2: -2 % there).
+        // that, in some bands, turns around on odd steps (the tail of one step is the head of the next and is still
+        // cached: -6 % at 2^22 envs in round 2) with the action rows streamed (bit 2: -2 % there).
         // Round 4, hover task in the derived-target layout (where the band was swept end to end, profiles/r04_ab/band_*.txt,
         // upper_*.txt): between ~400 MiB and ~1.1 GiB touched per step — a step that is one to four times the Infinity
         // Cache, the LRU worst case — the STATE loads carry the non-temporal hint (bit 3) on a plain round-robin sweep:
@@ -958,8 +958,14 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // lose 4 % to it at the same footprints (waypoint 1.75 M envs, race 2 M), the swarm task prefers order 6 there.
         const char* o = getenv("DRONE_SWEEP_ORDER");
         const bool hover_dt = cfg->task == DRONE_TASK_HOVER && dt;
-        uint32_t order = touched <= ((size_t)400 << 20) ? 1u : touched <= ((size_t)768 << 20) ? 0u : 6u;
-        if (hover_dt && touched > ((size_t)400 << 20) && touched <= ((size_t)1100 << 20)) order = 8u;
+        // The other tasks, and the bands around it (round 4 re-sweep of round 2's thresholds, profiles/r04_ab/sweep_*.txt:
+        // waypoint / swarm / race at 1.3 ... 4.2 M envs, orders 0 1 2 6 8): the reversed sweep pays between ~450 and ~600 MiB
+        // (-4 ... -10 % against a plain sweep) and again beyond ~900 MiB, but LOSES to a plain sweep in between, most at
+        // about three times the Infinity Cache (775 ... 835 MiB: +3 ... +12 %, all four tasks) — the old rule switched to it
+        // at 768 MiB, exactly there.
+        const size_t mib = touched >> 20;
+        uint32_t order = mib <= 400 ? 1u : mib <= 450 ? 0u : mib <= 600 ? 6u : mib <= 900 ? 0u : 6u;
+        if (hover_dt && mib > 400 && mib <= 1100) order = 8u;
         v->dv.order = (o && *o) ? (uint32_t)atoi(o) : order;
     }
     {   // Packed-f32 RK4 in the register-resident kernels (fused rollout, step_many): wins only while a SIMD holds ONE
