@@ -121,6 +121,20 @@ def test_plain_python_launch_with_gpus_2_starts_its_own_ranks(hip):
     assert d["host_boundary_gather"]["gather_peer_store"]["ms_per_step"] > 0
 
 
+def test_workload_argv():
+    """What the optional child job inherits from its parent's command line: the workload, nothing else."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.workload_argv(["--gpus", "8", "--steps", "20", "--warmup", "5"]) == ["--steps", "20", "--warmup", "5"]
+    assert bench.workload_argv(["--gpus=8", "--steps=20", "--value-from", "no_gather", "--task", "race", "--force-dist", "--total-envs=4096"]) == [
+        "--steps=20", "--task", "race", "--total-envs=4096"]
+    assert bench.workload_argv(["--phase", "core", "--optional-timeout", "45", "--seed", "7", "--no-extras", "--ring", "2"]) == ["--seed", "7", "--ring", "2"]
+    assert bench.workload_argv([]) == []
+    # every handle bench.py says it times is listed once
+    assert len({(t, n) for t, n, _ in bench.TIMED_HANDLES}) == len(bench.TIMED_HANDLES)
+
+
 def test_self_launch_returns_the_childrens_failure_without_a_gpu():
     """No GPU here: the ranks die on their first assert; the launcher must come back non-zero (and must not hang or print a line)."""
     import torch
