@@ -46,9 +46,13 @@ else:
     tok = open(tokfile, "rb").read()
 v.gather_init_peer(tok, flags, rank, world, root=root, counts=counts)
 crc = 0
+rounds = 0
 def consume():
-    global crc
+    global crc, rounds
     if rank != root: return
+    rounds += 1
+    if os.environ.get("SLOW_ROOT") and rounds <= 12:
+        time.sleep(0.03)  # a slow consumer: the other ranks have long finished this round and want to write the next one
     for t in g:  # stream-ordered copies behind the handshake's waits: the consumer of this round
         crc = zlib.crc32(t.cpu().numpy().tobytes(), crc)
 v.reset(seed); v.gather(); consume()
@@ -95,10 +99,16 @@ def run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_en
 
 
 @pytest.mark.parametrize("world,total,task,root,rollout,host_wait", [(2, 8192, 0, 0, 0, 0), (3, 7001, 1, 2, 0, 0), (2, 4096, 2, 1, 0, 0), (3, 6001, 3, 0, 16, 0),
-                                                                    (2, 5000, 0, 0, 0, 1)])
+                                                                    (2, 5000, 0, 0, 0, 1), (3, 9000, 0, 1, 0, 2), (2, 5000, 1, 0, 0, 3)])
 def test_peer_stores_land_every_ranks_rows_in_the_roots_batch(oracle, hip, tmp_path, world, total, task, root, rollout, host_wait):
+    """host_wait: 0 stream-side handshake, 1 host-side; 2 / 3: the same two with a SLOW consumer on the root (it sleeps
+    before reading the batch): the other ranks finish their round at once and must NOT overwrite their rows with the next
+    one until the root has begun its own next launch — the back-pressure half of the handshake."""
     steps, seed = 48, 23
-    res, out = run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env={"DRONE_PEER_HOST_WAIT": "1"} if host_wait else None)
+    extra = {"DRONE_PEER_HOST_WAIT": "1"} if host_wait in (1, 3) else {}
+    if host_wait >= 2:
+        extra["SLOW_ROOT"] = "1"
+    res, out = run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env=extra or None)
     assert all(rc == 0 for rc, _ in res.values()), "\n".join(f"--- rank {r}: rc {rc}\n{se[-1500:]}" for r, (rc, se) in res.items())
     over = dict(horizon=20)
     if task == 2:
