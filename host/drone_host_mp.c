@@ -114,6 +114,27 @@ typedef struct Opts {
     unsigned long long seed;
 } Opts;
 
+/* --exchange peer, the root's stand-in consumer: copy the batch from its HBM to the host — stream-ordered behind the
+ * handshake's waits (drone_vec_copy_to_host) — and chain the CRC over it. After a reset only the observations are defined. */
+typedef struct PeerBatch {
+    float *g_obs, *g_rew, *h_obs, *h_rew;
+    unsigned char *g_term, *g_trunc, *h_term, *h_trunc;
+    size_t total, od;
+} PeerBatch;
+
+static int peer_consume(DroneVec* v, const PeerBatch* b, int after_reset, uint32_t* crc) {
+    if (drone_vec_copy_to_host(v, b->h_obs, b->g_obs, sizeof(float) * b->total * b->od) != 0) return -1;
+    *crc = crc32_update(*crc, b->h_obs, sizeof(float) * b->total * b->od);
+    if (after_reset) return 0;
+    if (drone_vec_copy_to_host(v, b->h_rew, b->g_rew, sizeof(float) * b->total) != 0 || drone_vec_copy_to_host(v, b->h_term, b->g_term, b->total) != 0 ||
+        drone_vec_copy_to_host(v, b->h_trunc, b->g_trunc, b->total) != 0)
+        return -1;
+    *crc = crc32_update(*crc, b->h_rew, sizeof(float) * b->total);
+    *crc = crc32_update(*crc, b->h_term, b->total);
+    *crc = crc32_update(*crc, b->h_trunc, b->total);
+    return 0;
+}
+
 /* --exchange peer: one rank's whole run. Device-buffer handle with library-owned local buffers; the root's global batch
  * lives in its HBM (drone_device_malloc) and is copied to the host after every gather for the CRC. */
 static int run_rank_peer(const Opts* o, int rank, Shared* sh, void* flag_page) {
@@ -172,19 +193,10 @@ static int run_rank_peer(const Opts* o, int rank, Shared* sh, void* flag_page) {
     int sense = 0;
     if (rank == o->die_rank) raise(SIGKILL);
     uint32_t crc = 0;
-#define CONSUME(first)                                                                                                       \
-    do {                                                                                                                     \
-        if (rank == root && o->crc) { /* the root's consumer: the batch, behind the handshake's waits on the same stream */   \
-            if (drone_vec_copy_to_host(v, h_obs, g_obs, sizeof(float) * total * od) != 0 || ((first) ? 0 :                    \
-                (drone_vec_copy_to_host(v, h_rew, g_rew, sizeof(float) * total) != 0 || drone_vec_copy_to_host(v, h_term, g_term, total) != 0 || \
-                 drone_vec_copy_to_host(v, h_trunc, g_trunc, total) != 0))) { fprintf(stderr, "rank %d: %s\n", rank, drone_last_error()); return 1; } \
-            crc = crc32_update(crc, h_obs, sizeof(float) * total * od);                                                       \
-            if (!(first)) { crc = crc32_update(crc, h_rew, sizeof(float) * total); crc = crc32_update(crc, h_term, total); crc = crc32_update(crc, h_trunc, total); } \
-        }                                                                                                                    \
-    } while (0)
+    const PeerBatch pb = {g_obs, g_rew, h_obs, h_rew, g_term, g_trunc, h_term, h_trunc, total, od};
     drone_vec_reset(v, o->seed);
     if (drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
-    CONSUME(1);
+    if (rank == root && o->crc && peer_consume(v, &pb, 1, &crc) != 0) { fprintf(stderr, "rank %d: %s\n", rank, drone_last_error()); return 1; }
     const int launches = o->rollout > 0 ? (o->steps + o->rollout - 1) / o->rollout : o->steps;
     if (barrier(sh, world, &sense)) { fprintf(stderr, "rank %d: start barrier abandoned\n", rank); return 1; }
     const double t0 = now_s();
@@ -196,9 +208,8 @@ static int run_rank_peer(const Opts* o, int rank, Shared* sh, void* flag_page) {
             drone_vec_step(v);
         }
         if (drone_vec_gather(v) != 0) { fprintf(stderr, "rank %d: gather failed: %s\n", rank, drone_last_error()); return 1; }
-        CONSUME(0);
+        if (rank == root && o->crc && peer_consume(v, &pb, 0, &crc) != 0) { fprintf(stderr, "rank %d: %s\n", rank, drone_last_error()); return 1; }
     }
-#undef CONSUME
     if (drone_vec_sync(v) != 0) { fprintf(stderr, "rank %d: %s\n", rank, drone_last_error()); return 1; }
     sh->batch_crc[rank] = crc;
     sh->rank_crc[rank] = 0;
