@@ -108,6 +108,9 @@
 #define DRONE_EARLY_ARGS 2
 #endif
 
+#ifndef DRONE_SCALAR_RESET  // 1: the register-resident kernels hash the reset draws of ended episodes on the SCALAR unit, one ended lane at a time (lane_reset_wave), instead of in vector instructions for all 64 lanes. Measured (round 4, profiles/r04_ab/ab_sreset_*): -22 VALU instructions per wave-step, but the dependent scalar chain (~60 instructions per ended lane) stalls the wave: fused rollout -0.9 % at 2^20 envs, +2 % at 262 144, +7 % at 131 072; step_many K=32 +6 % at 2^20. Negative result: off
+#define DRONE_SCALAR_RESET 0
+#endif
 #ifndef DRONE_CARRY_ROTOR  // 1: the register-resident kernels carry the rotor inputs from step to step (Lane::u); 0: recompute them every step (A/B only)
 #define DRONE_CARRY_ROTOR 1
 #endif
@@ -477,16 +480,17 @@ __device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L,
 // CARRY: the state stays in registers from step to step and carries the rotor inputs (Lane::u) with it.
 // PK: the RK4 substep in packed f32 instructions (small shards; drone_pk.hpp).
 // INRANGE: `act` was drawn by random_action in this kernel (values in [-1, 1): the clamp of SPEC.md section 5 step 1 is the identity).
-template <int TASK, bool CARRY = false, bool PK = false, bool INRANGE = false>
+// SRESET: ended episodes' reset draws hashed on the scalar unit (lane_reset_wave): only where the whole wave is in the call.
+template <int TASK, bool CARRY = false, bool PK = false, bool INRANGE = false, bool SRESET = false>
 __device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     if (TASK == DRONE_TASK_SWARM) {
         StepCtx ctx;
         lane_integrate<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, ctx);
         float nn_d2, nn_e[3];
         swarm_neighbour(P, L, tile, nn_d2, nn_e);
-        lane_finish<TASK, CARRY>(P, L, env, ctx, nn_d2, out);
+        lane_finish<TASK, CARRY, SRESET>(P, L, env, ctx, nn_d2, out);
     } else {
-        lane_step<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, out);
+        lane_step<TASK, CARRY, PK, INRANGE, SRESET>(P, L, act, env, gstep, out);
     }
 }
 
@@ -773,7 +777,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, true>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, true, (DRONE_SCALAR_RESET != 0) && !PK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -846,7 +850,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     if (POLICY) random_action(P.key_action, env, gstep, act);
     else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
     StepOut out;
-    step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, POLICY>(P, L, tile, act, env, gstep, out);
+    step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, POLICY, (DRONE_SCALAR_RESET != 0) && !PK>(P, L, tile, act, env, gstep, out);
     const bool ended = out.oob || out.trunc;
     any_target |= out.target_changed;
     any_end |= ended;

@@ -353,14 +353,9 @@ DRONE_FN float target_dist(const Lane& L) {
     return sqrtf(fma_(dx, dx, fma_(dy, dy, dz * dz)));
 }
 
-// SPEC.md §6. `env` is the global env id.
+// SPEC.md §6 from the five reset draws u[0..4] of (env, episode): nine values from their 16-bit halves, low half first
 template <int TASK = DRONE_TASK_HOVER, bool CARRY = false>
-DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
-    const uint32_t b = rng_base(P.key_reset, env, L.episode);
-    // nine values from five draws: 16-bit halves, low half first (SPEC.md §6)
-    uint32_t u[5];
-#pragma unroll
-    for (uint32_t k = 0; k < 5; k++) u[k] = rng_draw(b, k);
+DRONE_FN void lane_reset_from_draws(const KParams& P, Lane& L, const uint32_t (&u)[5]) {
     float t[3];
 #pragma unroll
     for (uint32_t i = 0; i < 3; i++) {
@@ -400,6 +395,44 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     }
     if (CARRY) L.u = rotor_inputs(P, L.s.r);  // the carried rotor inputs follow the fresh rotor speeds
 }
+
+// SPEC.md §6. `env` is the global env id.
+template <int TASK = DRONE_TASK_HOVER, bool CARRY = false>
+DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
+    const uint32_t b = rng_base(P.key_reset, env, L.episode);
+    uint32_t u[5];
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) u[k] = rng_draw(b, k);
+    lane_reset_from_draws<TASK, CARRY>(P, L, u);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same for a whole wave in which SOME lanes' episodes ended (`ended`; every lane of the wave must call this), with the
+// six integer hashes of each ended lane computed on the SCALAR unit: an episode ends in about one lane-step of 146, so a
+// wave that has to run the reset at all has one or two lanes to reset, yet the vector form issues its ~50 hash instructions
+// for all 64. Here the wave walks the ballot mask, reads (env, episode) of one ended lane into SGPRs, hashes there
+// (s_mul_i32 / s_xor / s_lshr: they issue beside the other waves' VALU work) and hands the five draws to that lane with
+// one v_cndmask each. Integer arithmetic: bit-identical to the vector form by construction.
+template <int TASK, bool CARRY>
+__device__ __forceinline__ void lane_reset_wave(const KParams& P, Lane& L, uint32_t env, bool ended) {
+    uint32_t u[5] = {0u, 0u, 0u, 0u, 0u};
+    unsigned long long m = __ballot(ended);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    while (m) {  // wave-uniform
+        const int l = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t env_s = (uint32_t)__builtin_amdgcn_readlane((int)env, l), ep_s = (uint32_t)__builtin_amdgcn_readlane((int)L.episode, l);
+        const uint32_t b = rng_base(P.key_reset, env_s, ep_s);
+        const bool mine = lane == l;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            const uint32_t d = rng_draw(b, k);  // uniform: scalar unit
+            u[k] = mine ? d : u[k];             // one v_cndmask per draw hands it to its lane
+        }
+    }
+    if (ended) lane_reset_from_draws<TASK, CARRY>(P, L, u);
+}
+#endif
 
 // SPEC.md §2: the synthetic random policy.
 DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float (&a)[4]) {
@@ -490,7 +523,9 @@ DRONE_FN void nearest_neighbour(const KParams& P, Other other, float& nn_d2, flo
 
 // SPEC.md §5 steps 5–9 (§10 steps 6–7 for the swarm task): distance, bounds,
 // reward, episode end and reset. `nn_d2` is read only by the swarm task.
-template <int TASK, bool CARRY = false>
+// SRESET (device only): the reset of ended episodes hashes on the scalar unit (lane_reset_wave) — every lane of the wave
+// must then be in this call together (the register-resident kernels' step loops are).
+template <int TASK, bool CARRY = false, bool SRESET = false>
 DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx& ctx, float nn_d2, StepOut& out) {
     const float dist = target_dist(L);
     bool oob = !(fabsf(L.s.p[0]) <= P.bound) || !(fabsf(L.s.p[1]) <= P.bound) || !(fabsf(L.s.p[2]) <= P.bound);
@@ -563,18 +598,24 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
         out.ep_return = L.ep_return;
         out.ep_len = (float)L.tick;
         L.episode += 1u;
-        lane_reset<TASK, CARRY>(P, L, env);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!SRESET)
+#endif
+            lane_reset<TASK, CARRY>(P, L, env);
         target_changed = true;
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SRESET && __ballot(oob || trunc) != 0ull) lane_reset_wave<TASK, CARRY>(P, L, env, oob || trunc);
+#endif
     out.target_changed = target_changed;
 }
 
 // Single-agent tasks: the whole of SPEC.md §5 steps 1–9.
-template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT, bool INRANGE = false>
+template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT, bool INRANGE = false, bool SRESET = false>
 DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     StepCtx ctx;
     lane_integrate<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, ctx);
-    lane_finish<TASK, CARRY>(P, L, env, ctx, 0.0f, out);
+    lane_finish<TASK, CARRY, SRESET>(P, L, env, ctx, 0.0f, out);
 }
 
 // SPEC.md §7
