@@ -8,7 +8,10 @@ exchange is at the host boundary: an all-gather of observations / rewards /
 flags for a consumer that wants the whole batch on every rank (RCCL over xGMI
 when the tensors are in HBM; the same code runs on gloo with CPU tensors), or
 — ``RootGather`` — a gather to ONE rank for a single consumer process: every
-other rank sends its rows once and receives nothing.
+other rank sends its rows once and receives nothing; or — ``PeerStoreGather``
+(round 4) — no collective at all: the other ranks' step kernels write their
+rows straight into the root's IPC-mapped batch (``drone_vec_gather_init_peer``)
+and the "gather" is a flag handshake.
 """
 import contextlib
 
@@ -195,3 +198,62 @@ class PipelinedGather:
             gathered = self.gathers[i](*outs)
             self.done[i].record(self.comm)
         return gathered, self.done[i]
+
+
+class PeerStoreGather:
+    """The host-boundary exchange WITHOUT a collective, for torch consumers (``include/drone_vec.h``:
+    ``drone_vec_gather_peer_export`` / ``drone_vec_gather_init_peer``).
+
+    The root allocates the global batch in its HBM and exports it (IPC handles); the token and the name of a 4 KiB flag
+    page in ``/dev/shm`` travel over ``torch.distributed`` once, here in the constructor (any backend: it is the only use
+    of it); every rank then binds its env's OUTPUT pointers to its rows of the root's batch. From then on each rank's step
+    kernel stores its observations / rewards / flags into the root's memory itself — xGMI stores on the other GPUs of a
+    node — and ``__call__`` (once per launch on every rank, like the collectives) is only the handshake: the other ranks
+    publish "landed", the root's stream waits for all of them. Returns the global tensors on the root, ``None`` elsewhere.
+    The env's own ``observations`` / ``rewards`` / ... tensors are not written while this is active; ``close()`` hands
+    the env its buffers back. Device-buffer envs only (``binding.DroneVec`` with ``device=``)."""
+
+    def __init__(self, vec, total_envs, root=0, group=None, counts=None):
+        import os
+
+        import numpy as np
+
+        from . import abi
+
+        self.vec, self.group = vec, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.root = int(root)
+        self.total = int(total_envs)
+        self.counts = list(counts) if counts is not None else shard_counts(self.total, self.world)
+        dev, od = vec.torch_device, abi.obs_dim(vec.cfg.task)
+        self.obs = self.rew = self.term = self.trunc = None
+        box = [None, None]
+        self._flagfile = None
+        if self.rank == self.root:
+            self.obs = torch.zeros((self.total, od), dtype=torch.float32, device=dev)
+            self.rew = torch.zeros(self.total, dtype=torch.float32, device=dev)
+            self.term = torch.zeros(self.total, dtype=torch.uint8, device=dev)
+            self.trunc = torch.zeros(self.total, dtype=torch.uint8, device=dev)
+            self._flagfile = f"/dev/shm/drone_peer_flags_{os.getpid()}_{id(self) & 0xFFFFFF:x}"
+            with open(self._flagfile, "wb") as fh:
+                fh.write(b"\0" * 4096)
+            box = [vec.gather_peer_export(self.obs, self.rew, self.term, self.trunc), self._flagfile]
+        src = self.root if group is None else dist.get_global_rank(group, self.root)
+        dist.broadcast_object_list(box, src=src, group=group)
+        self._flags = np.memmap(box[1], dtype=np.uint32, mode="r+", shape=(1024,))  # one shared page, page-aligned
+        vec.gather_init_peer(box[0], self._flags, self.rank, self.world, root=self.root, counts=self.counts)
+
+    def __call__(self):
+        self.vec.gather()
+        return (self.obs, self.rew, self.term, self.trunc) if self.rank == self.root else None
+
+    def close(self):
+        import os
+
+        self.vec.gather_close()
+        dist.barrier(group=self.group)  # every rank has unmapped before the page's name goes
+        if self._flagfile:
+            os.unlink(self._flagfile)
+            self._flagfile = None
+        self._flags = None

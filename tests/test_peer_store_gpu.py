@@ -184,3 +184,67 @@ def test_plain_c_host_peer_store_with_a_dead_rank_ends(hip):
     r = subprocess.run([EXE_MP, "--gpus", "3", "--envs", "6000", "--steps", "10", "--share-devices", "1", "--exchange", "peer", "--die-rank", "1", "--timeout", "60"],
                        capture_output=True, text=True, timeout=200, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode != 0 and "ended abnormally" in r.stderr, r.stderr[-1500:]
+
+
+_WORKER_DIST = r"""
+import os, sys, zlib
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from drone_amd import binding
+from drone_amd.dist import PeerStoreGather, shard_range
+rank, world, total, task, steps, seed, root = (int(x) for x in sys.argv[1:8])
+store, out = sys.argv[8:10]
+dist.init_process_group("gloo", init_method="file://" + store, rank=rank, world_size=world)
+off, cnt = shard_range(total, rank, world)
+v = binding.DroneVec(cnt, seed=seed, cfg=binding.default_config(task, horizon=20, env_offset=off), device="cuda:0")
+ps = PeerStoreGather(v, total, root=root)   # export + token / flag page over torch.distributed + output rebinding, all in here
+crc = 0
+def consume(batch):
+    global crc
+    if batch is not None:
+        for t in batch:
+            crc = zlib.crc32(t.cpu().numpy().tobytes(), crc)
+v.reset(seed); consume(ps())
+for _ in range(steps):
+    v.fill_random_actions(); v.step(); consume(ps())
+torch.cuda.synchronize()
+ps.close()
+if rank == root:
+    np.savez(out, crc=np.uint32(crc))
+v.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,total,task,root", [(2, 6000, 0, 0), (3, 7003, 1, 1)])
+def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, world, total, task, root):
+    """drone_amd.dist.PeerStoreGather: the same exchange behind the helper torch consumers (and bench.py) use — the token and
+    the flag page's name cross torch.distributed (gloo here) once, in its constructor."""
+    steps, seed = 40, 29
+    script = tmp_path / "worker_dist.py"
+    script.write_text(_WORKER_DIST.format(root=ROOT))
+    store, out = str(tmp_path / "store"), str(tmp_path / "out.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)] + [str(x) for x in (r, world, total, task, steps, seed, root)] + [store, out], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    errs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=180)
+            errs.append((p.returncode, se))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(rc == 0 for rc, _ in errs), "\n".join(f"--- rc {rc}\n{se[-1500:]}" for rc, se in errs)
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=4)
+    o.reset(seed)
+    crc = 0
+    for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+        crc = zlib.crc32(buf.tobytes(), crc)
+    for _ in range(steps):
+        o.fill_random_actions()
+        o.step()
+        for buf in (o.observations, o.rewards, o.terminals, o.truncations):
+            crc = zlib.crc32(buf.tobytes(), crc)
+    assert int(np.load(out)["crc"]) == crc
