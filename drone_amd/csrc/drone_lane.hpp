@@ -25,7 +25,7 @@
 #ifndef DRONE_PK_DEFAULT
 #define DRONE_PK_DEFAULT 0
 #endif
-#if defined(DRONE_PARAMS_IN_LDS) && DRONE_PARAMS_IN_LDS
+#if (defined(DRONE_PARAMS_IN_LDS) && DRONE_PARAMS_IN_LDS) || (defined(DRONE_PARAMS_GLOBAL) && DRONE_PARAMS_GLOBAL)  // the packed form takes its constants as SGPR pairs: kernarg constants only
 #undef DRONE_PK_RK4
 #define DRONE_PK_RK4 0
 #endif
