@@ -104,7 +104,7 @@
 #define DRONE_STAMP(k) do {} while (0)
 #endif
 
-#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 0: wherever the compiler sinks their scalar loads (three dependent scalar-memory round trips ahead of the state loads); 1: all in the kernel's first scalar batch (one round trip); 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count: none). Round 4
+#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on (3: as 2, and the first chunk's vector loads are issued by hand ahead of the kernel's first scalar-memory wait — raw_issue / raw_land) — 0: wherever the compiler sinks their scalar loads (three dependent scalar-memory round trips ahead of the state loads); 1: all in the kernel's first scalar batch (one round trip); 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count: none). Round 4
 #define DRONE_EARLY_ARGS 2
 #endif
 
@@ -229,6 +229,51 @@ __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const fl
     } else {
         R.act = reinterpret_cast<const float4*>(actions)[ia];
     }
+}
+
+// ---- DRONE_EARLY_ARGS == 3: the first chunk's loads issued by hand (round 4) ----
+// A wave's first ~800 cycles at small shards are the round trip of its first scalar loads (the kernarg words beyond the
+// preloaded ones: the 57-word constants block), and the compiler parks an `s_waitcnt lgkmcnt(0)` AHEAD of the state loads
+// even when their addresses come out of preloaded SGPRs: later scalar loads reuse SGPRs of pending ones, and the only way
+// it knows to resolve that hazard is to drain. Issued as inline asm from the kernel's first instructions, the eight vector
+// loads depend on nothing that is pending, so the ~500 cycles of their latency overlap the scalar round trip instead of
+// following it. The compiler does not know these registers are in flight: nothing may touch them between `issue` and
+// `land` (no branch, no use — they are asm outputs consumed only by the asm that waits), and `land` waits for vmcnt(0):
+// these are the oldest vector-memory operations of the wave, so every later wait the compiler computes for its own
+// accesses is at worst early.
+template <int TASK>
+struct RawRegs {
+    f4_t a, b, c, d, e, t, w, act;
+};
+template <bool NT>
+__device__ __forceinline__ void asm_load(f4_t& dst, const void* p) {
+    if (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+template <int TASK, int MEM, bool DT>
+__device__ __forceinline__ void raw_issue(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawRegs<TASK>& r) {
+    constexpr bool NT_STATE = (MEM & 2) != 0 || DRONE_NT_STATE_LOADS, NT_ACT = (MEM & 1) != 0 || DRONE_NT_ACTION_LOADS;
+    constexpr uint32_t nph = hot_planes(TASK, DT);
+    asm_load<NT_STATE>(r.a, pl + hot_index(nph, kP0, i, np));
+    asm_load<NT_STATE>(r.b, pl + hot_index(nph, kP1, i, np));
+    asm_load<NT_STATE>(r.c, pl + hot_index(nph, kP2, i, np));
+    asm_load<NT_STATE>(r.d, pl + hot_index(nph, kP3, i, np));
+    asm_load<NT_STATE>(r.e, pl + hot_index(nph, kP4, i, np));
+    if (!DT) asm_load<NT_STATE>(r.t, pl + hot_index(nph, kPT, i, np));
+    if (has_aux_plane<TASK>()) asm_load<NT_STATE>(r.w, pl + hot_index(nph, kPW, i, np));
+    asm_load<NT_ACT>(r.act, reinterpret_cast<const float4*>(actions) + ia);
+}
+template <int TASK, bool DT>
+__device__ __forceinline__ void raw_land(RawRegs<TASK>& r, RawLane<TASK>& R) {
+    if (!DT && has_aux_plane<TASK>()) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.t), "+v"(r.w), "+v"(r.act));
+    else if (!DT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.t), "+v"(r.act));
+    else if (has_aux_plane<TASK>()) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.w), "+v"(r.act));
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.act));
+    auto f4 = [](const f4_t& x) { return make_float4(x.x, x.y, x.z, x.w); };
+    R.a = f4(r.a); R.b = f4(r.b); R.c = f4(r.c); R.d = f4(r.d); R.e = f4(r.e);
+    if (!DT) R.t = f4(r.t);
+    if (has_aux_plane<TASK>()) R.w = f4(r.w);
+    R.act = f4(r.act);
 }
 
 // the words of P4 and PT that are not floats: (tick, score_count, episode) and the target, for either layout
@@ -573,12 +618,29 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uin
 
 template <int TASK, bool COMPACT, int MEM, bool DT>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
+#define DRONE_ASM_FIRST_LOADS (DRONE_EARLY_ARGS == 3 && DRONE_STEP_TILES == 1 && !DRONE_STAMPS)
+#if DRONE_ASM_FIRST_LOADS
+    // the first (only) chunk's loads, from preloaded SGPRs and the thread id alone, ahead of everything. The sweep direction
+    // uses the step counter of the launch arguments: in graph-safe mode (device counters) that one is stale, which changes
+    // which workgroup takes which chunk — any bijection is correct — and nothing else.
+    RawRegs<TASK> early;
+    {
+        // my_chunk without control flow (selects): the loads must sit in the kernel's entry block, ahead of every wait
+        const uint32_t xcd = blockIdx.x & 7u, q = pre_nwg >> 3, r = pre_nwg & 7u;
+        const uint32_t c1 = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
+        uint32_t c = (pre_order & 1u) ? c1 : blockIdx.x;
+        c = ((pre_order & 2u) && (pre_gstep & 1u)) ? pre_nwg - 1u - c : c;
+        const uint32_t bb = c * (uint32_t)kBlock;
+        raw_issue<TASK, MEM, DT>(pre_planes, pre_act, pre_n_pad, bb + threadIdx.x, min(bb + threadIdx.x, pre_n - 1u), early);
+        __builtin_amdgcn_sched_barrier(0);  // nothing that follows (scalar loads of the rest of the arguments, their waits) may be scheduled above the loads
+    }
+#endif
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
-#if DRONE_EARLY_ARGS == 2
+#if DRONE_EARLY_ARGS >= 2
     a.v.planes = const_cast<float4*>(pre_planes); a.v.act = pre_act; a.v.ctr = const_cast<uint32_t*>(pre_ctr);
     a.v.n = pre_n; a.v.n_pad = pre_n_pad; a.v.order = pre_order; a.nwg = pre_nwg; a.gstep = pre_gstep; a.done_slot = pre_slot;
-#elif DRONE_EARLY_ARGS
+#elif DRONE_EARLY_ARGS == 1
     // A wave's first microsecond at small shards is its prologue: the state loads cannot go out before the scalar loads
     // of the words their addresses depend on have come back, and the compiler sank some of those (the plane pointers, the
     // hidden-argument grid size) behind branches — three dependent scalar-memory round trips. Naming them all here makes
@@ -598,14 +660,22 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
     // and hold a valid reset state: they load and compute like the rest and store nothing.
     const Counters ctr = read_counters(a);
     const uint32_t gstep = ctr.gstep, done_slot = ctr.launches & 1u;
+#if DRONE_ASM_FIRST_LOADS
+    uint32_t block_base = my_chunk(a.v.order, a.gstep, a.nwg) * (uint32_t)kBlock;  // the chunk whose loads are in flight (launch-argument step counter, see above)
+#else
     uint32_t block_base = my_chunk(a.v.order, gstep, a.nwg) * (uint32_t)(DRONE_STEP_TILES * kBlock);
+#endif
 #if DRONE_STAMPS
     unsigned long long stamp_[kStampSlots];
     stamp_[8] = __builtin_amdgcn_s_memrealtime();
 #endif
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
+#if DRONE_ASM_FIRST_LOADS
+    raw_land<TASK, DT>(early, cur);
+#else
     load_raw<TASK, MEM, DT>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
+#endif
 #if DRONE_EARLY_ARGS == 2
     // everything above came out of preloaded SGPRs: the state loads are in flight before the kernel's first scalar-memory
     // wait. Nothing may be scheduled across this point (a hoisted s_load + s_waitcnt, or a load sunk below one).
