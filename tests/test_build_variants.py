@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "drone_amd", "csrc")
 BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
         "-mllvm", "-amdgpu-kernarg-preload-count=12", "--cuda-device-only", "-c", "drone_kernels.hip", "-o", "/dev/null"]
-VARIANTS = ["-DDRONE_PARAMS_GLOBAL=1", "-DDRONE_STAMPS=1", "-DDRONE_EARLY_ARGS=0", "-DDRONE_SCALAR_RESET=1", "-DDRONE_STEP_TILES=2 -DDRONE_STEP_WAVE_OUTPUTS=1",
+VARIANTS = ["-DDRONE_PARAMS_GLOBAL=1", "-DDRONE_STAMPS=1", "-DDRONE_EARLY_ARGS=0", "-DDRONE_EARLY_ARGS=3", "-DDRONE_SCALAR_RESET=1", "-DDRONE_STEP_TILES=2 -DDRONE_STEP_WAVE_OUTPUTS=1",
             "-DDRONE_PK_RK4=0 -DDRONE_CARRY_ROTOR=0"]
 
 
