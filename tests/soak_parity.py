@@ -28,7 +28,8 @@ from drone_amd import abi  # noqa: E402
 from helpers import assert_bits_equal, assert_outputs_equal, assert_state_equal  # noqa: E402
 
 SIZES = [1, 2, 63, 64, 65, 127, 255, 256, 257, 1000, 1024, 4097, 8192, 16384 + 17, 32768]
-BIG_SIZES = [65536 + 1, 131072, 262144 + 65, 524288 - 63, 1048576, 1048576 + 3]  # --big: many workgroups per XCD, the size-dependent layout choices taken for real
+BIG_SIZES = [65536 + 1, 131072, 262144 + 65, 524288 - 63, 1048576, 1048576 + 3,  # --big: many workgroups per XCD, the size-dependent layout choices taken for real
+             1835008 + 1, 2621440, 3145728 - 63]  # round 4: footprints of 450 ... 900 MiB per step, where the sweep-order / non-temporal-load bands switch
 SCALED = ["mass", "arm", "ixx", "iyy", "izz", "k_thrust", "k_torque", "k_drag", "k_ang_damp", "motor_tau", "max_vel", "max_omega",
           "bound", "spawn_extent", "target_extent", "tilt_init", "hover_radius", "waypoint_radius", "wind_theta", "wind_sigma", "wind_max",
           "c_omega", "c_action", "crash_penalty", "progress_scale", "waypoint_bonus", "collision_radius", "proximity_radius", "c_proximity", "gate_radius"]
