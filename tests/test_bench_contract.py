@@ -33,7 +33,7 @@ def test_bench_line_has_the_contract_fields(hip):
     assert rf["traffic_measured_in_this_run"] in (True, False) and rf["traffic"] > 0 and rf["traffic"] == rf["traffic_detail"]["hbm_bytes_per_launch"]  # the contract's number: bytes per launch
     assert 0.97 < rf["traffic_over_algorithmic"] < 1.05, rf["traffic_detail"]
     if rf["traffic_measured_in_this_run"]:  # rocprofv3's own kernel durations on this box agree with the HIP events' launch average
-        assert rf["frac_from_rocprof_kernel_avg"] == pytest.approx(rf["frac"], rel=0.04), (rf["frac_from_rocprof_kernel_avg"], rf["frac"])
+        assert rf["frac_from_rocprof_kernel_avg"] == pytest.approx(rf["frac"], rel=0.08), (rf["frac_from_rocprof_kernel_avg"], rf["frac"])
     assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_env_step"] * rf["envs"] / (rf["launch_us"] * 1e-6) / 1e9)
     assert rf["frac_2pow22"] == rf["frac"] and rf["frac_of_measured_copy_peak"] == pytest.approx(rf["achieved"] / 6290.0)
     pts = rf["beyond_infinity_cache"]
