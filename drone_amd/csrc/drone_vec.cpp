@@ -964,7 +964,8 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // about three times the Infinity Cache (775 ... 835 MiB: +3 ... +12 %, all four tasks) — the old rule switched to it
         // at 768 MiB, exactly there.
         const size_t mib = touched >> 20;
-        uint32_t order = mib <= 400 ? 1u : mib <= 450 ? 0u : mib <= 600 ? 6u : mib <= 900 ? 0u : 6u;
+        const size_t rev_to = cfg->task == DRONE_TASK_SWARM ? 720 : 600;  // the swarm task keeps the reversed sweep's band longer (625 MiB: 103.2 against 116.1 us plain; 695: 124.3 / 130.4; 764: plain wins)
+        uint32_t order = mib <= 400 ? 1u : mib <= 450 ? 0u : mib <= rev_to ? 6u : mib <= 900 ? 0u : 6u;
         if (hover_dt && mib > 400 && mib <= 1100) order = 8u;
         v->dv.order = (o && *o) ? (uint32_t)atoi(o) : order;
     }
