@@ -686,7 +686,7 @@ static PyObject* host_pin_impl(PyObject* args, int pin) {
 static PyObject* vec_host_pin(PyObject* self, PyObject* args) { (void)self; return host_pin_impl(args, 1); }
 static PyObject* vec_host_unpin(PyObject* self, PyObject* args) { (void)self; return host_pin_impl(args, 0); }
 
-/* vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers */
+/* vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, 3 the same moved by the host copy pool, -1 device buffers */
 static PyObject* vec_variant(PyObject* self, PyObject* args) {
     (void)self;
     PyObject* cap;
@@ -749,7 +749,7 @@ static PyMethodDef methods[] = {
     {"vec_host_pin", vec_host_pin, METH_VARARGS, "vec_host_pin(handle, buffer, pages_exclusive=0): pin a page-owning host block for in-place access by vec_step_many"},
     {"vec_host_unpin", vec_host_unpin, METH_VARARGS, "vec_host_unpin(handle, buffer)"},
     {"vec_variant", vec_variant, METH_VARARGS, "vec_variant(handle) -> which per-step kernel instantiation and launch choices the env uses, as text (drone_vec_variant)"},
-    {"vec_host_transport", vec_host_transport, METH_VARARGS, "vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, -1 device buffers"},
+    {"vec_host_transport", vec_host_transport, METH_VARARGS, "vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, 3 the same moved by the host copy pool, -1 device buffers"},
     {"vec_sync", vec_sync, METH_VARARGS, "vec_sync(handle): wait until everything enqueued on the env's stream has finished"},
     {"obs_dim", obs_dim, METH_VARARGS, "obs_dim(task) -> floats per observation row"},
     {NULL, NULL, 0, NULL}};

@@ -347,10 +347,11 @@ class DroneVec:
     @property
     def host_transport(self):
         """'zero-copy' (the kernel reads / writes the pinned host buffers over PCIe), 'stand-in' (the same through
-        pinned stand-ins the library owns for buffers it may not pin, copied on the host around each step), 'mirror'
-        (device mirrors + DMA copies), or None for device buffers."""
+        pinned stand-ins the library owns for buffers it may not pin, copied on the host around each step), 'stand-in-mt'
+        (mid-size shards: the stand-ins moved by the library's host thread pool, the outputs while the kernel still runs),
+        'mirror' (device mirrors + DMA copies), or None for device buffers."""
         t = self._f["drone_vec_host_transport"](self._h)
-        return {1: "zero-copy", 2: "stand-in", 0: "mirror"}.get(t)
+        return {1: "zero-copy", 2: "stand-in", 3: "stand-in-mt", 0: "mirror"}.get(t)
 
     def enable_graph_capture(self, on=True):
         """Counters in HBM, advanced by the kernels: a captured step / rollout (torch.cuda.graph) replays correctly."""
@@ -435,6 +436,10 @@ class DroneVec:
     # -- checkpoint / resume: everything a run needs to continue bit for bit --
     # where the buffers live, and how the device lays the state out, are the resuming process's business (rows are layout-free)
     _CKPT_CFG_SKIP = ("struct_size", "buffer_kind", "device", "host_pages_exclusive", "state_layout")
+    # What the persisted rows MEAN is the spec's business: SPEC v5 (round 4) turned the hover / swarm per-env log sums from
+    # ratios into counts and changed the reset attitude, so a file written under v4 would load without complaint, mix the
+    # two kinds of sums and no longer continue bit for bit. Bump together with SPEC.md's version.
+    SPEC_VERSION = 5
 
     def save_checkpoint(self, path):
         """Write the shard's state rows, the vec-level step counter, the seed the RNG streams are keyed on, the env
@@ -444,15 +449,19 @@ class DroneVec:
         cfg = {k: v for k, v in self.cfg.as_dict().items() if k not in self._CKPT_CFG_SKIP}
         to_np = lambda x: x.cpu().numpy() if _is_torch(x) else np.asarray(x)  # noqa: E731
         with open(path, "wb") as fh:
-            np.savez(fh, rows=self.get_state(), gstep=np.uint32(self.gstep), seed=np.uint64(self._seed), num_envs=np.int64(self.num_envs),
+            np.savez(fh, spec_version=np.int64(self.SPEC_VERSION), rows=self.get_state(), gstep=np.uint32(self.gstep), seed=np.uint64(self._seed), num_envs=np.int64(self.num_envs),
                      cfg_keys=np.array(list(cfg.keys())), cfg_vals=np.array([float(v) for v in cfg.values()], dtype=np.float64),
                      observations=to_np(self.observations), actions=to_np(self.actions), rewards=to_np(self.rewards),
                      terminals=to_np(self.terminals), truncations=to_np(self.truncations))
 
     def load_checkpoint(self, path):
         """Restore a ``save_checkpoint`` file into this handle (same num_envs and env config; host or device buffers
-        alike). Refuses a file written under a different config or shard size rather than continuing a different env."""
+        alike). Refuses a file written under a different config, shard size or SPEC version rather than continuing a different env."""
         with np.load(path) as z:
+            ver = int(z["spec_version"]) if "spec_version" in z.files else 4  # files older than the field were written under SPEC v4 or earlier
+            if ver != self.SPEC_VERSION:
+                raise ValueError(f"checkpoint was written under SPEC v{ver}{' or earlier' if 'spec_version' not in z.files else ''}, this library implements "
+                                 f"SPEC v{self.SPEC_VERSION}: its log sums and reset draws mean something else (SPEC.md sections 6 and 8); it cannot continue bit for bit")
             if int(z["num_envs"]) != self.num_envs:
                 raise ValueError(f"checkpoint holds {int(z['num_envs'])} envs, this handle {self.num_envs}")
             mine = self.cfg.as_dict()

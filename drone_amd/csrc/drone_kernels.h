@@ -34,16 +34,38 @@ struct DeviceView {
     uint32_t* done_count;// [2] ping-pong per step launch, or null
 };
 
+// What a launch that writes the outputs publishes BY ITSELF (round 5), all null by default.
+// Peer-store exchange (drone_vec_gather_init_peer): the two flag publications of the handshake ride on the launch instead
+// of being launches of their own (a dependent launch boundary each: +2.65 us per step).
+//   ack (root): "my stream has reached my next launch" — whatever consumed the previous batch was enqueued ahead of this
+//     launch on the same stream, so the first workgroup may say so the moment the kernel starts: one relaxed system-scope
+//     store, no fence (it publishes no data).
+//   post (other ranks): "my launch has landed in the root's HBM" — every workgroup drains its stores (s_waitcnt vmcnt(0)
+//     in every wave, workgroup barrier), one lane makes them visible system-wide (release fence: this XCD's L2 written
+//     back) and counts the workgroup in; the workgroup whose count comes LAST publishes the flag (the arrival-counter
+//     idiom of advance_counters).
+// Host-buffer handles whose outputs go through pinned stand-ins (drone_vec_host_transport 3):
+//   wg_done: one word per 256-drone chunk, in ENV order, in pinned host memory. A workgroup of the per-step kernel stores
+//     wg_done_value there once its chunk's rows have been acknowledged (same drain + release), so that host threads can
+//     copy finished chunks to the caller's memory while the rest of the kernel is still writing over PCIe.
+struct LaunchSig {
+    uint32_t* ack_flag;    // host memory shared by the ranks (device-mapped), or null
+    uint32_t* post_flag;   // likewise, or null
+    uint32_t* arrive;      // HBM: workgroups of this launch that have released their stores; zero between launches
+    uint32_t* wg_done;     // pinned host memory (device-mapped): [chunks] words, or null
+    uint32_t ack_value, post_value, wg_done_value;
+};
+
 #ifndef DRONE_BLOCK  // workgroup size (tuning knob; multiple of 64)
 #define DRONE_BLOCK 256
 #endif
 constexpr int kBlock = DRONE_BLOCK;
 constexpr int kStampSlots = 10;  // -DDRONE_STAMPS=1: s_memtime at 8 points of the step kernel + s_memrealtime at entry and exit
 
-hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s);
+hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s, const LaunchSig* sig = nullptr);
 // done_slot: which done_count slot this launch adds to (compact_done); the kernel zeroes the other one for the next step launch
-hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s);
-hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s);
+hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s, const LaunchSig* sig = nullptr);
+hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s, const LaunchSig* sig = nullptr);
 // K env steps in one launch with per-step outputs into [K][n]... blocks; act == nullptr: the random policy in-kernel;
 // done_ids [K][n] + done_count [K] (zeroed by the caller on the same stream) or both null
 // act_stride: rows between the action blocks of consecutive steps (n: a [K][n][4] block; 0: one [n][4] block repeated)
@@ -56,8 +78,10 @@ hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid
 // Peer-store exchange (drone_vec_gather_init_peer): the handshake on the stream. post: everything this stream has written
 // so far (the step kernel's stores into the root's HBM) is visible system-wide, then *flag = value. wait: lane r polls
 // flags[r] (words in host memory shared by the ranks' processes; r < count, r != skip) until it has reached `want`,
-// sleeping between polls; a lane gives up after `budget_ticks` of the 100 MHz real-time counter and sets *err
-// (host-mapped) instead of spinning for ever. ONE launch for all the ranks waited for.
+// sleeping between polls; the wave gives up after `budget_ticks` of the 100 MHz real-time counter and sets *err
+// (host-mapped) instead of spinning for ever — and returns AT ONCE when *err is already set (an earlier wait of this
+// handle gave up: the waits a caller has queued behind it must not spin their budgets one after the other).
+// ONE launch for all the ranks waited for.
 hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s);
 hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s);
 

@@ -114,6 +114,15 @@
 #ifndef DRONE_CARRY_ROTOR  // 1: the register-resident kernels carry the rotor inputs from step to step (Lane::u); 0: recompute them every step (A/B only)
 #define DRONE_CARRY_ROTOR 1
 #endif
+#ifndef DRONE_PRIO_ROTATE  // 1: the register-resident kernels rotate s_setprio among the waves that share a SIMD (PrioRotor below); 0: the hardware's oldest-first arbitration (A/B)
+#define DRONE_PRIO_ROTATE 1
+#endif
+#ifndef DRONE_PRIO_ROTATE_MANY  // the same in the K-steps-per-launch kernel. Off: that kernel has no scalar register to spare (the one word of state costs the swarm / waypoint instantiations 100-180 v_readlane / v_writelane spills)
+#define DRONE_PRIO_ROTATE_MANY 0
+#endif
+#ifndef DRONE_PRIO_PERIOD_LOG2  // the priorities move on every 2^k env steps
+#define DRONE_PRIO_PERIOD_LOG2 3
+#endif
 #ifndef DRONE_ROLLOUT_MIN_WAVES  // __launch_bounds__ 2nd argument of the fused rollout kernel; 0 = unset
 #define DRONE_ROLLOUT_MIN_WAVES 0
 #endif
@@ -364,6 +373,7 @@ struct StepArgs {
     uint32_t flags_aligned;  // bit0: terminals 16-B aligned, bit1: truncations 16-B aligned
     uint32_t done_slot;      // which of the two done-list counters this step launch adds to (the host alternates per STEP launch)
     uint32_t nwg;            // workgroups of this launch (= gridDim.x, which the kernel would otherwise fetch from the hidden arguments in a scalar round trip of its own)
+    LaunchSig sig;           // what this launch publishes itself (drone_kernels.h): peer-store handshake flags, per-chunk completion words; all null otherwise
 #if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     KParams kp;              // constants by value: scalar loads from the kernarg segment
 #endif
@@ -577,6 +587,36 @@ __device__ __forceinline__ void advance_counters(const StepArgs& a, const Counte
     }
 }
 
+// Peer-store exchange: the handshake's two publications from inside the launch that writes the outputs (LaunchSig).
+// ack: the root's stream has reached this launch, so whatever consumed the previous batch is done (stream order); one
+// relaxed system-scope store by the first lane of the grid — it carries no data, so no fence.
+__device__ __forceinline__ void peer_ack(const StepArgs& a) {
+    if (a.sig.ack_flag && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.sig.ack_flag, a.sig.ack_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// post / wg_done: called by EVERY thread of EVERY workgroup as the kernel's last statement (it contains a workgroup barrier);
+// `chunk`: the 256-drone chunk (env order) this workgroup wrote.
+// A flag may only become visible behind all the rows this workgroup (wg_done) or this launch (post) stored — into the root's
+// buffers (remote HBM on a multi-GPU node) or into pinned host memory over PCIe: each wave waits for its own stores to be
+// acknowledged, the workgroup meets, one lane writes this XCD's L2 back at system scope (a release fence; the asm wait behind
+// it keeps the compiler from dropping the fence's own wait — MI355X_MICROARCH.md "Compiler hazard"). Then, wg_done: the chunk's
+// word; post: the workgroup counts itself in with a device-scope atomic, and the one whose count comes last knows that every
+// other workgroup's release completed before its add, and publishes the flag.
+__device__ __forceinline__ void peer_post(const StepArgs& a, uint32_t chunk) {
+    if (!a.sig.post_flag && !a.sig.wg_done) return;  // launch-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.sig.wg_done) __hip_atomic_store(a.sig.wg_done + chunk, a.sig.wg_done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.sig.post_flag && atomicAdd(a.sig.arrive, 1u) == gridDim.x - 1u) {
+            __hip_atomic_store(a.sig.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the kernel boundary publishes it to the next launch
+            __hip_atomic_store(a.sig.post_flag, a.sig.post_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // which 256-drone chunk this workgroup owns. `order` (a launch argument, chosen by the host from the step's
 // footprint; DeviceView::order) — bit 0: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the
 // envs instead of being dealt round-robin over one global sweep; bits 2 and 3: non-temporal action / state loads (load_raw);
@@ -682,6 +722,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
     __builtin_amdgcn_sched_barrier(0);
 #endif
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
+    peer_ack(a);
 #pragma unroll
     for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
         const uint32_t i = block_base + threadIdx.x;
@@ -781,6 +822,7 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
         cur = nxt;
     }
     advance_counters(a, ctr, 1u, 1u);
+    peer_post(a, block_base / (uint32_t)kBlock);  // (the loop above leaves by its break: block_base is still the chunk just written; per-chunk words assume DRONE_STEP_TILES == 1)
 }
 
 // =====================================================================
@@ -793,6 +835,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t block_base = blockIdx.x * kBlock;
     const uint32_t i = block_base + threadIdx.x;
+    peer_ack(a);
     Lane L;
     L.episode = 0u;
     lane_reset<TASK>(P, L, P.env_offset + i);
@@ -804,7 +847,52 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     float o[DRONE_OBS_DIM_MAX];
     obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
     write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, false, false, i, block_base);
+    peer_post(a, blockIdx.x);
 }
+
+// Fair shares of a SIMD for the register-resident kernels (round 5). VALU issue is arbitrated among the waves
+// of a SIMD by priority, then AGE: with every wave at priority 0 the oldest runs as if alone (1852 cycles per env step of the
+// hover rollout), the second gets what is left (3186), a third and fourth almost nothing (tools/wg_census.py: the four waves of
+// a SIMD at 262 144 envs end after 106, 150, 210 and 266 us). The SIMD's total rate is the same either way while all of them
+// are resident — but they leave one by one, and the last wave of a SIMD runs ALONE, at the single-wave issue rate (one VALU
+// per 4.5 cycles against 2.5-2.8 for the SIMD with company), for the last 20-45 % of the launch. Rotating the priorities —
+// every 2^DRONE_PRIO_PERIOD_LOG2 env steps the waves move on one place in a cycle of `mod` priority levels, each starting from
+// its hardware wave slot (HW_ID[3:0]: distinct among the waves resident on one SIMD) — keeps them level, so they finish
+// together and the SIMD is shared to the end. `mod` = waves resident per SIMD for this launch (2 ... 4; the host knows the
+// grid and the kernel's register budget), 0 / 1 = off (a lone wave per SIMD has nobody to share with). Scalar unit only; the
+// priority is a speed hint, never a result.
+struct PrioRotor {
+    uint32_t x;  // ONE scalar register (the register-resident kernels have none to spare): bits 1:0 this wave's priority now, bits 3:2 levels - 1 (0 = off)
+    __device__ __forceinline__ void set() const {
+        switch (x & 3u) {  // s_setprio takes an immediate
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
+    __device__ __forceinline__ void init(uint32_t m) {
+        const uint32_t mod = (DRONE_PRIO_ROTATE && m >= 2u) ? (m > 4u ? 4u : m) : 0u;
+        x = 0u;
+        if (mod) {
+            uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_REG_HW_ID bits 3:0: this wave's slot on its SIMD
+            while (slot >= mod) slot -= mod;
+            x = ((mod - 1u) << 2) | slot;
+            set();
+        }
+    }
+    // before env step t of the launch; the priorities move on when (t & mask) == 0
+    __device__ __forceinline__ void tick(uint32_t t, uint32_t mask) {
+        if ((x >> 2) && t != 0u && (t & mask) == 0u) {
+            const uint32_t p = (x & 3u) + 1u;
+            x = (x & 12u) | (p > (x >> 2) ? 0u : p);
+            set();
+        }
+    }
+    __device__ __forceinline__ void done() const {
+        if (x >> 2) __builtin_amdgcn_s_setprio(0);
+    }
+};
 
 // =====================================================================
 // fused rollout (SPEC.md §9): config 5. State stays in registers for the
@@ -823,7 +911,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
 #endif
 
 template <int TASK, bool PK>
-__global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
+__global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(StepArgs a, uint32_t horizon, uint32_t prio_mod) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
@@ -838,12 +926,16 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
+    peer_ack(a);
     float rsum = 0.0f;
     bool any_term = false, any_trunc = false, any_target = false;
 #if DRONE_STAMPS  // diagnostic build: the shader clock this kernel holds = delta s_memtime / delta s_memrealtime x 100 MHz (tools/rollout_clock.py)
     const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    PrioRotor prio;
+    prio.init(prio_mod);
     for (uint32_t t = 0; t < horizon; t++) {
+        prio.tick(t, (1u << DRONE_PRIO_PERIOD_LOG2) - 1u);
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
@@ -854,11 +946,15 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         any_target |= out.target_changed;
         if (out.oob || out.trunc) fold_log(l0, l1, out);
     }
+    prio.done();
 #if DRONE_STAMPS
     asm volatile("" ::"v"(rsum), "v"(L.s.p[0]));
     if (a.v.stamps && (threadIdx.x & (kWave - 1)) == 0) {
         unsigned long long* row = a.v.stamps + (size_t)(i / kWave) * kStampSlots;
         row[0] = ck0; row[1] = __builtin_amdgcn_s_memtime(); row[8] = rt0; row[9] = __builtin_amdgcn_s_memrealtime();
+        // where this wave ran (tools/wg_census.py): HW_REG_HW_ID (wave / SIMD / CU / shader array / shader engine) and HW_REG_XCC_ID
+        row[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        row[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
@@ -872,6 +968,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     obs_any<TASK>(P, L, sh.obs_tile[threadIdx.x / kWave], o);
     write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, any_term, any_trunc, i, block_base);
     advance_counters(a, ctr, horizon, 0u);  // a rollout builds no done-id list: the step-launch counter stays
+    peer_post(a, block_base / (uint32_t)kBlock);
 }
 
 // =====================================================================
@@ -904,6 +1001,7 @@ struct ManyArgs {
     uint32_t* done_ids;    // [K][n] (compact_done) or null
     uint32_t* done_count;  // [K], zeroed by the host before the launch
     uint32_t k_steps;
+    uint32_t prio_mod;     // waves resident per SIMD in this launch (PrioRotor), 0 / 1 = no rotation
 };
 
 // one env step of the K: everything between "action row in registers" and "outputs of step k issued".
@@ -968,13 +1066,24 @@ __device__ __forceinline__ void many_loop(const KParams& P, Shared& sh, const St
         a_cur = actp[0];
         a_nxt = actp[(size_t)min(1u, K - 1u) * m.act_stride];
     }
+    // short launches rotate the SIMD's priorities every step, long ones every second / eighth (PrioRotor)
+#if DRONE_PRIO_ROTATE_MANY
+    PrioRotor prio;
+    prio.init(m.prio_mod);
+#endif
     // step 0, peeled: the loop below is entered with step 0's stores behind the load of a_nxt, like every later entry
     many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, 0u, gstep0, i, block_base, any_target, any_end);
     for (uint32_t k = 1; k < K; k++) {
+#if DRONE_PRIO_ROTATE_MANY
+        prio.tick(k, K >= 64u ? 7u : K >= 16u ? 1u : 0u);
+#endif
         a_cur = a_nxt;
         if (!POLICY) a_nxt = actp[(size_t)min(k + 1u, K - 1u) * m.act_stride];  // the NEXT step's row: in flight during this step's arithmetic
         many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, k, gstep0 + k, i, block_base, any_target, any_end);
     }
+#if DRONE_PRIO_ROTATE_MANY
+    prio.done();
+#endif
 }
 
 #ifndef DRONE_MANY_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the K-steps-per-launch kernel; 0 = unset
@@ -1070,19 +1179,25 @@ __global__ __launch_bounds__(64) void drone_flag_post_kernel(uint32_t* flag, uin
     }
 }
 
-// One launch waits for ALL the flags it is given: lane r polls flag r (r < count, r != skip); the wave retires when every
-// lane has seen its flag reach `want` or has run out of budget.
+// One launch waits for ALL the flags it is given: lane l polls flags l, l + 64, ... (r < count, r != skip); the wave — all
+// lanes together, the loop is wave-uniform — retires when every flag has reached `want`, when the time budget has run
+// out (lane 0 then raises *err), or AT ONCE when *err is already raised: an earlier wait of this handle gave up (a dead
+// peer), and a caller that does not sync every launch has queued every later step's wait behind it — each would
+// otherwise spin its full budget in turn. The error word is loaded together with the flags (both live in
+// host memory: one PCIe round trip either way).
 __global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks) {
-    for (uint32_t r = threadIdx.x; r < count; r += 64u) {
-        if (r == skip) continue;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((int32_t)(__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-            __builtin_amdgcn_s_sleep(64);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
-                __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const uint32_t failed = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        bool ok = true;
+        for (uint32_t r = threadIdx.x; r < count; r += 64u)
+            if (r != skip) ok = ok && (int32_t)(__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0;
+        if (__all(ok) || failed != 0u) break;  // wave-uniform (err is one address: every lane read the same word)
+        if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
+            if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
         }
+        __builtin_amdgcn_s_sleep(64);
     }
 }
 
@@ -1092,6 +1207,7 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     a.gstep = gstep;
     a.done_slot = 0;
     a.nwg = 0;  // set by the launchers that deal chunks (step, rollout, step_many)
+    a.sig = LaunchSig{nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
 #if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     a.kp = *v.kp_host;
@@ -1100,6 +1216,20 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
 }
 
 inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+// How many waves of a launch of `nwg` workgroups share a SIMD while it runs: the dispatcher deals workgroups evenly over the
+// 256 CUs (tools/wg_census.py: exactly nwg / 256 per CU at every size tried), a workgroup puts kBlock / 64 / 4 waves on each of a
+// CU's four SIMDs, and `cap` is what the kernel's registers admit. DRONE_PRIO_MOD=<n> overrides (tuning; 1 = rotation off).
+inline uint32_t resident_waves_per_simd(uint32_t nwg, uint32_t cap) {
+    static const int forced = [] { const char* e = getenv("DRONE_PRIO_MOD"); return (e && *e) ? atoi(e) : -1; }();
+    if (forced >= 0) return (uint32_t)forced;
+    int cus = 256;
+    static const int dev_cus = [] { int d = 0, n = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256; }();
+    cus = dev_cus;
+    const uint32_t per_wg = kBlock / 64u >= 4u ? kBlock / 256u : 1u;
+    const uint32_t w = ((nwg + (uint32_t)cus - 1u) / (uint32_t)cus) * per_wg;
+    return w < cap ? w : cap;
+}
 
 // The packed-f32 RK4 form for the register-resident kernels: chosen per handle by the host (DeviceView::packed_rk4)
 inline bool use_packed(const DeviceView& v) { return DRONE_PK_RK4 && v.packed_rk4 != 0; }
@@ -1111,19 +1241,22 @@ inline void drop_stale_error() { (void)hipGetLastError(); }
 
 }  // namespace
 
-hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s) {
+hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s, const LaunchSig* sig) {
     drop_stale_error();
     const dim3 g(v.n_pad / kBlock), b(kBlock);
-    if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(make_args(v, 0));
-    else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(make_args(v, 0));
-    else if (task == DRONE_TASK_WAYPOINT) drone_reset_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(make_args(v, 0));  // its tiles carry the wind plane
-    else drone_reset_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(make_args(v, 0));
+    StepArgs a = make_args(v, 0);
+    if (sig) a.sig = *sig;
+    if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(a);
+    else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(a);
+    else if (task == DRONE_TASK_WAYPOINT) drone_reset_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(a);  // its tiles carry the wind plane
+    else drone_reset_kernel<DRONE_TASK_HOVER><<<g, b, 0, s>>>(a);
     return hipGetLastError();
 }
 
-hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s) {
+hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t done_slot, hipStream_t s, const LaunchSig* sig) {
     drop_stale_error();
     StepArgs a = make_args(v, gstep);
+    if (sig) a.sig = *sig;
     a.done_slot = done_slot & 1u;
     const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
     a.nwg = g.x;
@@ -1151,13 +1284,15 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     return hipGetLastError();
 }
 
-hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s) {
+hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32_t horizon, hipStream_t s, const LaunchSig* sig) {
     drop_stale_error();
     StepArgs a = make_args(v, gstep0);
+    if (sig) a.sig = *sig;
     const dim3 g(grid_for(v.n)), b(kBlock);
     a.nwg = g.x;
     const bool pk = use_packed(v);
-#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon); } while (0)
+    const uint32_t prio_mod = resident_waves_per_simd(g.x, 4u);  // (every rollout instantiation takes 104-128 VGPRs: four waves per SIMD)
+#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon, prio_mod); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon, prio_mod); } while (0)
     if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_HOVER);
     else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_SWARM);
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_RACE);
@@ -1174,6 +1309,7 @@ hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint
     ManyArgs m;
     m.act = act; m.act_stride = act_stride; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
     m.done_ids = done_ids; m.done_count = done_count; m.k_steps = k_steps;
+    m.prio_mod = resident_waves_per_simd(a.nwg, 2u);  // 176-204 VGPRs: two waves per SIMD
     const dim3 g(grid_for(v.n)), b(kBlock);
     const bool compact = done_ids != nullptr, policy = act == nullptr, pk = use_packed(v);
 #define DRONE_LAUNCH_MANY2(T, C, PO) do { if (pk) drone_step_many_kernel<T, C, PO, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, C, PO, false><<<g, b, 0, s>>>(a, m); } while (0)

@@ -23,6 +23,7 @@
 
 #include <rccl/rccl.h>  // types only: the library is dlopen'ed on first use (drone_vec_gather_init), never linked
 
+#include "drone_host_copy.hpp"
 #include "drone_kernels.h"
 
 using namespace drone;
@@ -110,6 +111,17 @@ struct DroneVec {
     // The kernel reads / writes the stand-in over PCIe; the host copies between it and the caller's buffer around the step.
     void* bounce[5];
     size_t bounce_bytes[5];
+    // zero_copy with stand-ins too large for one memcpy around the step (round 5, drone_vec_host_transport 3): the host copy
+    // pool moves them — the action rows in as parallel slices, the outputs out WHILE the step kernel runs, chunk by chunk as
+    // its workgroups raise their words in h_wg_done (LaunchSig::wg_done)
+    bool threaded;
+    uint32_t* h_wg_done;  // pinned + mapped: one word per 256-drone chunk, env order
+    uint32_t* d_wg_done;  // its device address
+    uint32_t n_wg;
+    uint32_t wg_seq;      // what a chunk's word reads once the CURRENT step's rows of that chunk have landed
+    bool copy_started;    // the pool is delivering this handle's outputs (from step_send until step_recv / the end of step)
+    int stream_idle;      // set (atomically) by the calling thread once the stream is known to have drained: nothing is left to wait for, copy the rest
+    int copy_abort;       // ... or to have failed: stop
     float* m_obs;        // device-visible addresses of the caller's registered host buffers or of their stand-ins (zero_copy)
     float* m_act;
     float* m_rew;
@@ -133,7 +145,11 @@ struct DroneVec {
     // blocks drone_vec_host_pin registered on this handle (and only those: host_unpin drops nothing else)
     void* pinned_blocks[64];
     int n_pinned_blocks;
-    char variant[192];   // drone_vec_variant
+    char variant[448];   // drone_vec_variant
+    // round 5: the sweep order / load hints of an HBM-bound handle are MEASURED on the box it runs on, once, at the first reset
+    // (autotune_sweep); the footprint table of drone_vec_init only nominates the candidates
+    bool autotune_pending;
+    size_t touched_mib;  // MiB one step touches (the footprint the table is indexed by)
     // sticky status: the first failure of any call on this handle (drone_vec_status)
     int status;
     char status_msg[512];
@@ -253,9 +269,68 @@ bool validate(const DroneConfig* c, int num_envs) {
     return true;
 }
 
+// ---- the host copy pool's jobs (transport 3) ----
+// a slice of `bytes` for part `part` of `parts`, cut at 4 KiB so that no two threads share a page
+void slice_of(size_t bytes, int part, int parts, size_t& begin, size_t& end) {
+    const size_t per = ((bytes + (size_t)parts - 1) / (size_t)parts + 4095u) & ~(size_t)4095u;
+    begin = per * (size_t)part < bytes ? per * (size_t)part : bytes;
+    end = begin + per < bytes ? begin + per : bytes;
+}
+void copy_actions_part(void* ctx, int part, int parts) {
+    DroneVec* v = static_cast<DroneVec*>(ctx);
+    size_t b, e;
+    slice_of(v->bounce_bytes[1], part, parts, b, e);
+    if (b < e) memcpy(static_cast<char*>(v->bounce[1]) + b, reinterpret_cast<const char*>(v->u_act) + b, e - b);
+}
+// every stand-in of an output buffer, whole (reset, rollout: launches that raise no per-chunk words)
+void copy_all_outputs_part(void* ctx, int part, int parts) {
+    DroneVec* v = static_cast<DroneVec*>(ctx);
+    void* const dst[5] = {v->u_obs, nullptr, v->u_rew, v->u_term, v->u_trunc};
+    for (int k : {0, 2, 3, 4}) {
+        if (!v->bounce[k]) continue;
+        size_t b, e;
+        slice_of(v->bounce_bytes[k], part, parts, b, e);
+        if (b < e) memcpy(static_cast<char*>(dst[k]) + b, static_cast<const char*>(v->bounce[k]) + b, e - b);
+    }
+}
+// rows of the chunks [c0, c1) of every output stand-in
+void copy_chunks(DroneVec* v, uint32_t c0, uint32_t c1) {
+    const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task) * sizeof(float);
+    const size_t r0 = (size_t)c0 * kBlock, r1 = (size_t)c1 * kBlock < n ? (size_t)c1 * kBlock : n;
+    if (r0 >= r1) return;
+    if (v->bounce[0]) memcpy(reinterpret_cast<char*>(v->u_obs) + r0 * od, static_cast<const char*>(v->bounce[0]) + r0 * od, (r1 - r0) * od);
+    if (v->bounce[2]) memcpy(v->u_rew + r0, static_cast<const float*>(v->bounce[2]) + r0, (r1 - r0) * sizeof(float));
+    if (v->bounce[3]) memcpy(v->u_term + r0, static_cast<const unsigned char*>(v->bounce[3]) + r0, r1 - r0);
+    if (v->bounce[4]) memcpy(v->u_trunc + r0, static_cast<const unsigned char*>(v->bounce[4]) + r0, r1 - r0);
+}
+// The step's outputs, while the kernel runs: this thread owns a contiguous share of the chunks and copies every run of
+// chunks whose words have turned to the step's sequence number. The words are an accelerator, not the contract: once the
+// calling thread has seen the stream drain (stream_idle) everything has landed and the rest is copied without looking.
+void copy_outputs_part(void* ctx, int part, int parts) {
+    DroneVec* v = static_cast<DroneVec*>(ctx);
+    const uint32_t c0 = (uint32_t)((uint64_t)v->n_wg * (uint32_t)part / (uint32_t)parts), c1 = (uint32_t)((uint64_t)v->n_wg * (uint32_t)(part + 1) / (uint32_t)parts);
+    const uint32_t seq = v->wg_seq;
+    bool idle = false;
+    for (uint32_t c = c0; c < c1;) {
+        uint32_t e = c;
+        while (e < c1 && (idle || __atomic_load_n(v->h_wg_done + e, __ATOMIC_ACQUIRE) == seq)) e++;
+        if (e == c) {
+            if (__atomic_load_n(&v->copy_abort, __ATOMIC_ACQUIRE)) return;
+            if (__atomic_load_n(&v->stream_idle, __ATOMIC_ACQUIRE)) idle = true;
+            else CopyPool::cpu_relax();
+            continue;
+        }
+        copy_chunks(v, c, e);
+        c = e;
+    }
+}
+
 bool host_to_device_actions(DroneVec* v) {
     if (v->zero_copy) {  // the kernel reads the caller's action buffer itself, or its pinned stand-in
-        if (v->bounce[1]) memcpy(v->bounce[1], v->u_act, v->bounce_bytes[1]);
+        if (v->bounce[1]) {
+            if (v->threaded) CopyPool::get().run(copy_actions_part, v);
+            else memcpy(v->bounce[1], v->u_act, v->bounce_bytes[1]);
+        }
         return true;
     }
     HIP_TRY(hipMemcpyAsync(v->d_act, v->u_act, (size_t)v->n * DRONE_ACT_DIM * sizeof(float), hipMemcpyHostToDevice, v->stream), return false);
@@ -329,9 +404,35 @@ bool enqueue_host_outputs(DroneVec* v) {
     return true;
 }
 
+// the calling thread's part of a threaded copy-out, then the wait for the helpers — during which it keeps an eye on the stream:
+// drained = everything has landed, the helpers need not look at the words any more; failed = they must stop
+bool finish_threaded_copy(DroneVec* v) {
+    CopyPool& pool = CopyPool::get();
+    struct Watch {
+        static void poll(void* ctx) {
+            DroneVec* h = static_cast<DroneVec*>(ctx);
+            const hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) __atomic_store_n(&h->stream_idle, 1, __ATOMIC_RELEASE);
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); __atomic_store_n(&h->copy_abort, 1, __ATOMIC_RELEASE); }
+        }
+    };
+    pool.finish(Watch::poll, v);
+    v->copy_started = false;
+    if (__atomic_load_n(&v->copy_abort, __ATOMIC_ACQUIRE)) { set_err("the stream failed while the step's outputs were being delivered"); return false; }
+    return true;
+}
+
 bool finish_host_outputs(DroneVec* v) {
     if (v->zero_copy) {  // outputs already landed in the caller's memory (or its stand-ins): just wait for the kernel
+        if (v->copy_started) {  // transport 3, a step: the pool has been copying chunks out since the launch
+            const bool ok = finish_threaded_copy(v);
+            return wait_zero_copy(v) && ok;
+        }
         if (!wait_zero_copy(v)) return false;
+        if (v->threaded) {
+            CopyPool::get().run(copy_all_outputs_part, v);
+            return true;
+        }
         if (v->bounce[0]) memcpy(v->u_obs, v->bounce[0], v->bounce_bytes[0]);
         if (v->bounce[2]) memcpy(v->u_rew, v->bounce[2], v->bounce_bytes[2]);
         if (v->bounce[3]) memcpy(v->u_term, v->bounce[3], v->bounce_bytes[3]);
@@ -391,6 +492,7 @@ void unpin_if_rebound(DroneVec* v, int slot, const void* now) {
 }
 
 void drop_bounce(DroneVec* v) {
+    v->threaded = false;
     for (int k = 0; k < 5; k++) {
         if (v->bounce[k]) (void)hipHostFree(v->bounce[k]);
         v->bounce[k] = nullptr;
@@ -551,6 +653,12 @@ struct Gather {
     unsigned long long budget_ticks = 0; // of the 100 MHz real-time counter
     uint32_t seq = 0;                    // rounds this rank has published (non-root) / collected (root)
     uint32_t acked = 0;                  // root: last round whose consumption it has announced
+    // round 5: the two publications ride on the launch that writes the outputs (drone_kernels.h LaunchSig) instead of being
+    // one-wave launches of their own. DRONE_PEER_INKERNEL=0 keeps the separate launches (A/B; also what the host-side and
+    // hipStreamWriteValue32 forms use).
+    bool in_kernel = true;
+    uint32_t* d_arrive = nullptr;        // HBM: the arrival counter of the in-kernel post (non-root ranks)
+    uint32_t launch_posts = 0;           // non-root: the round the LAST output-writing launch publishes by itself when it ends (0: none)
     float* own_obs = nullptr; float* own_rew = nullptr; unsigned char* own_term = nullptr; unsigned char* own_trunc = nullptr;  // the handle's output bindings before the exchange took them over
 };
 
@@ -570,6 +678,10 @@ void gather_destroy(DroneVec* v) {
             if (g->peer_base[k]) (void)hipIpcCloseMemHandle(g->peer_base[k]);
         if (g->flags_registered) host_unregister(const_cast<uint32_t*>(g->flags), v, "peer-store flag page");
         if (g->h_err) (void)hipHostFree(g->h_err);
+        if (g->d_arrive) (void)hipFree(g->d_arrive);
+        // the export is consumed: a later drone_vec_gather_init_peer needs a fresh drone_vec_gather_peer_export (ADVICE r4:
+        // stale pointers here would be reused for buffers the caller may have freed since)
+        v->px_obs = nullptr; v->px_rew = nullptr; v->px_term = nullptr; v->px_trunc = nullptr;
     }
     void* hosts[4] = {g->h_obs, g->h_rew, g->h_term, g->h_trunc};
     for (int k = 0; k < 4; k++)
@@ -590,9 +702,15 @@ void gather_destroy(DroneVec* v) {
 // flags waited for (hipStreamWaitValue32 cannot: it takes only the calling process's signal memory), each lane giving up
 // after the time budget and raising the handle's error word; or, with DRONE_PEER_HOST_WAIT=1, on the host (drain the
 // stream, poll), where the same budget (DRONE_PEER_TIMEOUT_MS, default 10 s) makes a dead peer an immediate error.
+// DRONE_PEER_TIMEOUT_MS, clamped to [1 ms, 10 min]; anything malformed, zero or negative is the default (0 made every
+// wait give up at once, a negative value became a budget of centuries)
 long peer_timeout_ms() {
     const char* t = getenv("DRONE_PEER_TIMEOUT_MS");
-    return (t && *t) ? atol(t) : 10000;
+    if (!t || !*t) return 10000;
+    char* end = nullptr;
+    const long ms = strtol(t, &end, 10);
+    if (end == t || *end != 0 || ms < 1) return 10000;
+    return ms > 600000 ? 600000 : ms;
 }
 
 // flags [first, first + count) except `skip` (-1: none) have all reached `want`
@@ -653,20 +771,106 @@ bool peer_check_err(Gather* g) {
 
 // Before any launch that writes the output buffers (reset, step, rollout): the back-pressure half of the handshake.
 // A non-root rank's kernel is about to overwrite its rows of the root's buffers with round seq + 1: it may, once the
-// root has said that round seq has been consumed. The root says so here, at the start of ITS next launch — the
+// root has said that round seq has been consumed. The root says so at the start of ITS next launch — the
 // consumer's reads were enqueued on the same stream between drone_vec_gather and this call, so they are ordered ahead.
-bool peer_before_launch(DroneVec* v) {
+// `sig` (zeroed by the caller): what the launch that follows publishes by itself (round 5) — the root's acknowledgement
+// from its first workgroup as the kernel starts, a non-root rank's "round seq + 1 has landed" from the last workgroup to
+// finish — so that neither is a one-wave launch of its own; with DRONE_PEER_INKERNEL=0, host-side waits or
+// hipStreamWriteValue32 they stay separate and `sig` stays empty.
+bool peer_before_launch(DroneVec* v, LaunchSig* sig) {
     Gather* g = v->gather;
-    if (!g || !g->peer || g->seq == 0) return true;
+    if (!g || !g->peer) return true;
+    const bool in_kernel = g->in_kernel && g->gpu_waits && !g->stream_writes;
+    if (g->rank != g->root) {
+        g->launch_posts = 0;
+        if (in_kernel) {
+            sig->post_flag = reinterpret_cast<uint32_t*>(g->d_flags + 4 * g->rank);
+            sig->post_value = g->seq + 1u;
+            sig->arrive = g->d_arrive;
+            g->launch_posts = sig->post_value;
+        }
+    }
+    if (g->seq == 0) return true;
     if (!peer_check_err(g)) return false;
     if (g->rank == g->root) {
         if (g->acked != g->seq) {
-            if (!peer_post(v, g, g->world, g->seq)) return false;
+            if (in_kernel) {
+                sig->ack_flag = reinterpret_cast<uint32_t*>(g->d_flags + 4 * g->world);
+                sig->ack_value = g->seq;
+            } else if (!peer_post(v, g, g->world, g->seq)) {
+                return false;
+            }
             g->acked = g->seq;
         }
         return true;
     }
     return peer_wait_ge(v, g, g->world, 1, -1, g->seq);
+}
+
+// drone_vec_variant's text; `tuned`: " autotuned=1 tried=o0:181.2,o6:177.0,o8:175.3" once the first reset has measured the candidates
+void write_variant(DroneVec* v, const char* tuned) {
+    snprintf(v->variant, sizeof(v->variant), "drone_step_kernel<task=%d,compact=%d,mem=%u,dt=%d> order=%u line_complete=%u packed_rk4=%u bytes=%d%s",
+             v->cfg.task, v->dv.done_ids ? 1 : 0, (v->dv.order >> 2) & 3u, v->dv.derived_target ? 1 : 0, v->dv.order, v->dv.line_complete,
+             v->dv.packed_rk4, drone_vec_bytes_per_env_step(v), tuned ? tuned : "");
+}
+
+// Pick the per-step kernel's sweep order / load hints by MEASUREMENT (round 5). Candidates: the footprint table's entry and
+// its neighbours — a plain round-robin sweep (0), the sweep that turns around on odd steps with streamed action rows (6), a
+// plain sweep with non-temporal state loads (8) — all instantiations the parity suite covers (tests/soak_parity.py,
+// test_robustness_gpu.py: the order only permutes which workgroup takes which chunk and which loads carry a hint, never a
+// result). Timed on THIS handle's own planes and buffers — memory placement alone moves these kernels by several per cent,
+// so a scratch copy would measure another kernel — right behind a reset, in interleaved rounds of eight launches per
+// candidate with the step counter advancing (the reversed sweep keys on its parity); the caller's reset launch that follows
+// rewrites every plane, counter and output the trial steps touched. Costs ~75 launches once per handle (13 ms at 2^22 envs).
+// The whole-line widening of rare plane updates stays with the table: no episode ends this soon after a reset, so the trial
+// cannot see what it is for.
+void autotune_sweep(DroneVec* v) {
+    v->autotune_pending = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(v->stream, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cap != hipStreamCaptureStatusNone || v->dv.ctr || (v->gather && v->gather->peer)) return;  // nothing may be replayed, advanced on the device or stored into a peer's batch by a trial
+    const uint32_t table = v->dv.order;
+    uint32_t cand[4] = {table, 0u, 6u, 8u};
+    int nc = 1;
+    for (int k = 1; k < 4; k++)
+        if (cand[k] != table) cand[nc++] = cand[k];
+    float total[4] = {0.f, 0.f, 0.f, 0.f};
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // its own pair: a caller's drone_vec_timer_start may be pending on the handle's
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        return;
+    }
+    bool ok = launch_reset(v->dv, v->cfg.task, v->stream) == hipSuccess;
+    uint32_t g = 0;
+    const int rounds = 3, per_round = 8;
+    for (int r = -1; r < rounds && ok; r++) {  // round -1: untimed, brings the clocks and the caches to where a run keeps them
+        for (int c = 0; c < nc && ok; c++) {
+            v->dv.order = cand[c];
+            ok = ok && hipEventRecord(e0, v->stream) == hipSuccess;
+            for (int k = 0; k < per_round && ok; k++, g++) ok = launch_step(v->dv, v->cfg.task, g, g & 1u, v->stream) == hipSuccess;
+            ok = ok && hipEventRecord(e1, v->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+            float ms = 0.f;
+            ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (r >= 0) total[c] += ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) {  // leave the table's choice; the reset that follows reports whatever is wrong with the stream
+        (void)hipGetLastError();
+        v->dv.order = table;
+        return;
+    }
+    int best = 0;
+    for (int c = 1; c < nc; c++)
+        if (total[c] < total[best]) best = c;
+    v->dv.order = cand[best];
+    char tuned[200];
+    int at = snprintf(tuned, sizeof(tuned), " autotuned=1 table=%u tried=", table);
+    for (int c = 0; c < nc && at < (int)sizeof(tuned) - 16; c++)
+        at += snprintf(tuned + at, sizeof(tuned) - at, "%so%u:%.1f", c ? "," : "", cand[c], total[c] * 1e3f / (rounds * per_round));
+    write_variant(v, tuned);
 }
 
 }  // namespace
@@ -744,7 +948,7 @@ int drone_vec_host_transport(const DroneVec* v) {
     if (!v || !v->host_buffers) return -1;
     if (!v->zero_copy) return 0;
     for (int k = 0; k < 5; k++)
-        if (v->bounce[k]) return 2;
+        if (v->bounce[k]) return v->threaded ? 3 : 2;
     return 1;
 }
 
@@ -884,7 +1088,15 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // mirror transport's DMA copies: up to DRONE_HOST_BOUNCE_MAX_BYTES in total (default 1 MiB; 0 = never).
         const char* bm = getenv("DRONE_HOST_BOUNCE_MAX_BYTES");
         const size_t bounce_max = (bm && *bm) ? (size_t)atoll(bm) : ((size_t)1 << 20);
-        if (want_zero_copy(num_envs) && unpinned_bytes <= bounce_max) {
+        // Round 5: beyond that budget — the mid-size shards of a vec-env whose slices cannot be pinned, 16 384
+        // to ~10^5 envs — the stand-ins are moved by the host copy pool instead (drone_host_copy.hpp; transport 3): the action
+        // rows in as parallel slices, the outputs out chunk by chunk while the kernel is still writing over PCIe. Up to
+        // DRONE_HOST_MT_MAX_BYTES (default 64 MiB of unpinnable buffers; beyond, the step is PCIe-bound for milliseconds and the
+        // mirror transport's DMA copies are as good); DRONE_HOST_COPY_THREADS=1 (no pool) keeps the mirror transport.
+        const char* mm = getenv("DRONE_HOST_MT_MAX_BYTES");
+        const size_t mt_max = (mm && *mm) ? (size_t)atoll(mm) : ((size_t)64 << 20);
+        const bool threaded = bounce_max > 0 && unpinned_bytes > bounce_max && unpinned_bytes <= mt_max && CopyPool::get().parts() > 1;  // (a budget of 0 turns stand-ins of either kind off)
+        if (want_zero_copy(num_envs) && (unpinned_bytes <= bounce_max || threaded)) {
             void* mapped[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             bool have_all = true;
             for (int k = 0; k < 5 && have_all; k++) {
@@ -904,8 +1116,23 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
             const bool ok = v->m_obs && v->m_act && v->m_rew && v->m_term && v->m_trunc &&
                             !(reinterpret_cast<uintptr_t>(v->m_obs) & 15u) && !(reinterpret_cast<uintptr_t>(v->m_act) & 15u) &&
                             !(reinterpret_cast<uintptr_t>(v->m_rew) & 3u);
-            if (ok) {
+            bool words = true;
+            if (ok && threaded) {  // the per-chunk completion words
+                v->n_wg = v->n_pad / (uint32_t)kBlock;
+                void* hw = nullptr;
+                words = hipHostMalloc(&hw, sizeof(uint32_t) * v->n_wg, hipHostMallocMapped) == hipSuccess;
+                if (words) {
+                    v->h_wg_done = static_cast<uint32_t*>(hw);
+                    memset(hw, 0, sizeof(uint32_t) * v->n_wg);
+                    v->d_wg_done = static_cast<uint32_t*>(mapped_ptr(hw));
+                    words = v->d_wg_done != nullptr;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (ok && words) {
                 v->zero_copy = true;
+                v->threaded = threaded;
                 ensure_flag(v);
                 v->dv.obs = v->m_obs; v->dv.act = v->m_act; v->dv.rew = v->m_rew; v->dv.term = v->m_term; v->dv.trunc = v->m_trunc;
             } else {
@@ -968,6 +1195,14 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         uint32_t order = mib <= 400 ? 1u : mib <= 450 ? 0u : mib <= rev_to ? 6u : mib <= 900 ? 0u : 6u;
         if (hover_dt && mib > 400 && mib <= 1100) order = 8u;
         v->dv.order = (o && *o) ? (uint32_t)atoi(o) : order;
+        // Beyond 400 MiB the table's entry is only the FIRST candidate: the adopted differences between the orders there
+        // (-1.8 ... -3 % at 2^22 envs) are smaller than the spread of one binary across boxes of the pool (+-5 %), and the
+        // driver's box disagreed with the table at 2^22 against 2^23. The first reset times the candidates
+        // on this box, on this handle's own buffers (autotune_sweep). Not for a forced order, host buffers (PCIe-bound at
+        // these sizes) or DRONE_AUTOTUNE=0.
+        const char* at = getenv("DRONE_AUTOTUNE");
+        v->touched_mib = mib;
+        v->autotune_pending = mib > 400 && !(o && *o) && !v->host_buffers && !(at && *at && atoi(at) == 0);
     }
     {   // Packed-f32 RK4 in the register-resident kernels (fused rollout, step_many): wins only while a SIMD holds ONE
         // wave (<= 65 536 envs on the 1024 SIMDs: rollout -8.8 %, step_many -3.9 %; waypoint / race -3...4 %), where the
@@ -980,9 +1215,7 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
     v->dv.kp = v->d_kp;
     v->dv.kp_host = &v->kp;
     if (!upload_params(v)) { drone_vec_close(v); return nullptr; }
-    snprintf(v->variant, sizeof(v->variant), "drone_step_kernel<task=%d,compact=%d,mem=%u,dt=%d> order=%u line_complete=%u packed_rk4=%u bytes=%d",
-             cfg->task, v->dv.done_ids ? 1 : 0, (v->dv.order >> 2) & 3u, v->dv.derived_target ? 1 : 0, v->dv.order, v->dv.line_complete,
-             v->dv.packed_rk4, drone_vec_bytes_per_env_step(v));
+    write_variant(v, nullptr);
 #undef INIT_TRY
     if (debug_reg()) fprintf(stderr, "[drone reg] init %p n=%d %s%s obs=%p act=%p planes=%p\n", (void*)v, v->n, v->host_buffers ? "host" : "device", v->zero_copy ? " zero-copy" : "", (void*)observations, (void*)actions, (void*)v->dv.planes);
     return v;
@@ -996,21 +1229,37 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
     v->list_valid = false;
     v->many_k = 0;
-    if (!upload_params(v) || !push_counters(v) || !peer_before_launch(v)) return;
-    HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream), return);
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    if (!upload_params(v)) return;
+    if (v->autotune_pending) autotune_sweep(v);  // first reset of an HBM-bound handle: measure the sweep order on this box (the launch below restores everything)
+    if (!push_counters(v) || !peer_before_launch(v, &sig)) return;
+    HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream, &sig), return);
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
 namespace {
 bool step_send_impl(DroneVec* v) {
     if (v->host_buffers && !host_to_device_actions(v)) return false;
-    if (!peer_before_launch(v)) return false;
-    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream), return false);
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    if (!peer_before_launch(v, &sig)) return false;
+    const bool copy_out = v->host_buffers && v->zero_copy && v->threaded && v->h_flag;  // (without the completion flag the plain wait + whole copy is used)
+    if (copy_out) {
+        sig.wg_done = v->d_wg_done;
+        sig.wg_done_value = ++v->wg_seq;
+    }
+    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream, &sig), return false);
     v->gstep += 1;
     v->step_launches += 1;
     v->list_valid = true;
     v->many_k = 0;
-    return !v->host_buffers || enqueue_host_outputs(v);
+    if (!v->host_buffers) return true;
+    if (!enqueue_host_outputs(v)) return false;
+    if (copy_out) {  // the helpers start following the chunks' words now; the caller joins in finish_host_outputs
+        __atomic_store_n(&v->stream_idle, 0, __ATOMIC_RELEASE);
+        __atomic_store_n(&v->copy_abort, 0, __ATOMIC_RELEASE);
+        v->copy_started = CopyPool::get().try_start(copy_outputs_part, v);  // (busy with another handle's step: this one's outputs are copied after the wait, by this thread)
+    }
+    return true;
 }
 }  // namespace
 
@@ -1038,8 +1287,9 @@ void drone_vec_rollout(DroneVec* v, int horizon) {
     Entry in(v);
     if (!in || !idle(v, "rollout")) return;
     if (horizon <= 0) { set_err("rollout: horizon must be positive, got %d", horizon); return; }
-    if (!peer_before_launch(v)) return;
-    HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream), return);
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    if (!peer_before_launch(v, &sig)) return;
+    HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream, &sig), return);
     v->gstep += (uint32_t)horizon;
     v->list_valid = false;  // the fused rollout builds no done-id list
     v->many_k = 0;
@@ -1102,6 +1352,10 @@ void step_many_impl(DroneVec* v, int k_steps, const float* actions, bool repeat,
     if (!in || !idle(v, "step_many")) return;
     if (k_steps < 1) { set_err("step_many: k_steps must be positive, got %d", k_steps); return; }
     if (!observations || !rewards || !terminals || !truncations) { set_err("step_many: NULL output block"); return; }
+    if (v->gather && v->gather->peer) {  // it writes the caller's blocks, not this rank's rows of the root's batch, and runs outside the handshake
+        set_err("step_many / step_repeat: not while the peer-store exchange is active (the root's batch holds one step per round; drone_vec_gather_close first)");
+        return;
+    }
     const size_t n = (size_t)v->n, od = (size_t)drone_obs_dim(v->cfg.task), K = (size_t)k_steps;
     // Host handles: blocks the caller pinned beforehand (drone_host_pin, hipHostMalloc, hipHostRegister) are accessed by
     // the kernel in place over PCIe — no staging, no copy commands; anything else goes through device staging and DMA.
@@ -1186,7 +1440,9 @@ void drone_vec_close(DroneVec* v) {
     if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
+    if (v->copy_started) (void)finish_threaded_copy(v);  // closed between step_send and step_recv: the pool must let go of this handle first
     gather_destroy(v);
+    if (v->h_wg_done) (void)hipHostFree(v->h_wg_done);
     for (int i = 0; i < 5; i++)
         if (v->registered[i]) host_unregister(v->registered_ptr[i], v, "caller buffer at close");
     for (int i = 0; i < v->n_pinned_blocks; i++) host_unregister(v->pinned_blocks[i], v, "drone_vec_host_pin block at close");
@@ -1332,6 +1588,10 @@ int drone_vec_enable_graph_capture(DroneVec* v, int on) {
     Entry in(v);
     if (!in || !idle(v, "enable_graph_capture")) return -1;
     if (v->host_buffers) { set_err("graph-safe stepping needs device buffers (host-buffer steps end in a stream sync, which cannot be captured)"); return -1; }
+    if (on && v->gather && v->gather->peer) {  // the round numbers of the handshake are launch arguments kept by the host; a replay would wait for / publish a stale round
+        set_err("graph-safe stepping cannot be combined with the peer-store exchange (its handshake's round numbers are host state baked into each launch); drone_vec_gather_close first");
+        return -1;
+    }
     if (on && !v->dv.ctr) {
         HIP_TRY(hipMalloc((void**)&v->dv.ctr, 3 * sizeof(uint32_t)), return -1);
         if (!push_counters(v)) return -1;
@@ -1687,6 +1947,7 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
     if (!in || !idle(v, "gather_init_peer")) return -1;
     if (v->gather) { set_err("gather already initialised on this handle"); return -1; }
     if (v->host_buffers) { set_err("gather_init_peer: the peer-store exchange needs device buffers"); return -1; }
+    if (v->dv.ctr) { set_err("gather_init_peer: not on a handle in graph-safe mode (drone_vec_enable_graph_capture): a captured launch would replay the handshake with a stale round number"); return -1; }
     if (!token || !shared_flags || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) { set_err("gather_init_peer: bad token / flags / rank %d / world %d / root %d", rank, world, root); return -1; }
     if ((reinterpret_cast<uintptr_t>(shared_flags) % kPage) != 0 || (size_t)(world + 1) * 4u > kPage) { set_err("gather_init_peer: the flag block must be one 4 KiB page of memory shared by all ranks, page-aligned (world <= 1023)"); return -1; }
     if (rank == root && !v->px_obs) { set_err("gather_init_peer: the root must export its global buffers first (drone_vec_gather_peer_export)"); return -1; }
@@ -1718,6 +1979,12 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
     if (hw && *hw && atoi(hw) != 0) g->gpu_waits = false;
     const char* sw = getenv("DRONE_PEER_STREAM_WRITES");  // 1: publish flags with hipStreamWriteValue32 where the runtime takes the page
     if (sw && *sw) g->stream_writes = atoi(sw) != 0;
+    const char* ik = getenv("DRONE_PEER_INKERNEL");       // 0: the flag publications as one-wave launches of their own (round 4's form; A/B)
+    if (ik && *ik) g->in_kernel = atoi(ik) != 0;
+    if (rank != root && g->in_kernel && g->gpu_waits && !g->stream_writes) {
+        HIP_TRY(hipMalloc((void**)&g->d_arrive, 64), { gather_destroy(v); return -1; });
+        HIP_TRY(hipMemsetAsync(g->d_arrive, 0, 64, v->stream), { gather_destroy(v); return -1; });
+    }
     if (g->gpu_waits) {
         void* he = nullptr;
         HIP_TRY(hipHostMalloc(&he, 64, hipHostMallocMapped), { gather_destroy(v); return -1; });
@@ -1770,7 +2037,12 @@ int drone_vec_gather(DroneVec* v) {
         // "my launch #seq has landed" behind its kernel; the root's stream waits until every other rank has said so.
         if (!peer_check_err(g)) return -1;
         g->seq += 1u;
-        if (g->rank != g->root) return peer_post(v, g, g->rank, g->seq) ? 0 : -1;
+        if (g->rank != g->root) {
+            // the launch this call follows publishes the round itself when its last workgroup ends (LaunchSig): nothing to enqueue.
+            // Anything else (the separate-launch forms; a gather that follows no launch) gets the one-wave post.
+            if (g->launch_posts == g->seq) { g->launch_posts = 0; return 0; }
+            return peer_post(v, g, g->rank, g->seq) ? 0 : -1;
+        }
         if (g->world > 1 && !peer_wait_ge(v, g, 0, g->world, g->root, g->seq)) return -1;
         return 0;
     }

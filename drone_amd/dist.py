@@ -215,6 +215,7 @@ class PeerStoreGather:
 
     def __init__(self, vec, total_envs, root=0, group=None, counts=None):
         import os
+        import secrets
 
         import numpy as np
 
@@ -230,30 +231,49 @@ class PeerStoreGather:
         self.obs = self.rew = self.term = self.trunc = None
         box = [None, None]
         self._flagfile = None
-        if self.rank == self.root:
-            self.obs = torch.zeros((self.total, od), dtype=torch.float32, device=dev)
-            self.rew = torch.zeros(self.total, dtype=torch.float32, device=dev)
-            self.term = torch.zeros(self.total, dtype=torch.uint8, device=dev)
-            self.trunc = torch.zeros(self.total, dtype=torch.uint8, device=dev)
-            self._flagfile = f"/dev/shm/drone_peer_flags_{os.getpid()}_{id(self) & 0xFFFFFF:x}"
-            with open(self._flagfile, "wb") as fh:
-                fh.write(b"\0" * 4096)
-            box = [vec.gather_peer_export(self.obs, self.rew, self.term, self.trunc), self._flagfile]
         src = self.root if group is None else dist.get_global_rank(group, self.root)
-        dist.broadcast_object_list(box, src=src, group=group)
-        self._flags = np.memmap(box[1], dtype=np.uint32, mode="r+", shape=(1024,))  # one shared page, page-aligned
-        vec.gather_init_peer(box[0], self._flags, self.rank, self.world, root=self.root, counts=self.counts)
+        try:
+            if self.rank == self.root:
+                self.obs = torch.zeros((self.total, od), dtype=torch.float32, device=dev)
+                self.rew = torch.zeros(self.total, dtype=torch.float32, device=dev)
+                self.term = torch.zeros(self.total, dtype=torch.uint8, device=dev)
+                self.trunc = torch.zeros(self.total, dtype=torch.uint8, device=dev)
+                # a fresh name, created exclusively (never an existing file or a symlink someone planted under a guessable name), private to this user
+                name = f"/dev/shm/drone_peer_flags_{os.getpid()}_{secrets.token_hex(8)}"
+                fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
+                self._flagfile = name
+                try:
+                    os.write(fd, b"\0" * 4096)
+                finally:
+                    os.close(fd)
+                box = [vec.gather_peer_export(self.obs, self.rew, self.term, self.trunc), self._flagfile]
+        finally:
+            # every rank reaches the broadcast, also when the root failed above: the others then see [None, None] and raise instead of hanging
+            dist.broadcast_object_list(box, src=src, group=group)
+        try:
+            if box[0] is None:
+                raise RuntimeError("PeerStoreGather: the root could not export its batch")
+            self._flags = np.memmap(box[1], dtype=np.uint32, mode="r+", shape=(1024,))  # one shared page, page-aligned
+            vec.gather_init_peer(box[0], self._flags, self.rank, self.world, root=self.root, counts=self.counts)
+            dist.barrier(group=group)  # every rank has mapped the page: its NAME can go now, the memory lives as long as the mappings
+        finally:
+            self._unlink()
+
+    def _unlink(self):
+        import os
+
+        if self._flagfile:
+            try:
+                os.unlink(self._flagfile)
+            except OSError:
+                pass
+            self._flagfile = None
 
     def __call__(self):
         self.vec.gather()
         return (self.obs, self.rew, self.term, self.trunc) if self.rank == self.root else None
 
     def close(self):
-        import os
-
         self.vec.gather_close()
-        dist.barrier(group=self.group)  # every rank has unmapped before the page's name goes
-        if self._flagfile:
-            os.unlink(self._flagfile)
-            self._flagfile = None
+        self._unlink()  # (already gone: unlinked in the constructor once every rank had mapped it)
         self._flags = None

@@ -129,8 +129,14 @@ const char* drone_vec_variant(const DroneVec* v);
 /* How host-buffer steps of this handle move their data: 1 = zero-copy (the kernel reads / writes the caller's pinned
  * buffers over PCIe); 2 = zero-copy through pinned stand-ins the library owns for those of the five buffers that could
  * not be pinned themselves, copied to / from the caller's memory on the host around each step (small shards only:
- * DRONE_HOST_BOUNCE_MAX_BYTES, default 1 MiB of such buffers); 0 = device mirrors and DMA copies; -1 for device-buffer
- * handles. */
+ * DRONE_HOST_BOUNCE_MAX_BYTES, default 1 MiB of such buffers); 3 (round 5) = the same stand-ins for mid-size shards (up to
+ * DRONE_HOST_MT_MAX_BYTES, default 64 MiB of unpinnable buffers — a vec-env worker's unaligned shared-memory slices at
+ * 16 384 ... ~10^5 envs), moved by a small pool of host threads (DRONE_HOST_COPY_THREADS per job, caller included; default
+ * 4, 1 = off): the action rows go in as parallel slices, and the outputs come out WHILE the step kernel is still writing
+ * over PCIe — each 256-drone chunk as soon as its workgroup says its rows have landed. The pool is one per process, started
+ * on first use; its threads spin for ~200 us after a job and sleep otherwise; it serves one handle at a time (from
+ * drone_vec_step_send to drone_vec_step_recv it belongs to that handle): a second handle stepped meanwhile does its own
+ * copying on the calling thread. Do not fork() a process that has started it. 0 = device mirrors and DMA copies; -1 for device-buffer handles. */
 int drone_vec_host_transport(const DroneVec* v);
 
 /* Floats per observation row for a task: 20, or 24 for DRONE_TASK_SWARM and DRONE_TASK_RACE. */
@@ -308,15 +314,24 @@ void drone_vec_gather_close(DroneVec* v);
  * drone_vec_gather_init_peer. From then on each rank's kernels write observations / rewards / flags straight into that
  * rank's rows of the ROOT's buffers — local HBM on the root, stores over xGMI everywhere else: no collective launch, no
  * second pass over the outputs, nothing received or written by the other GPUs. drone_vec_gather is then only a
- * handshake, one call per launch on every rank as with RCCL: a non-root rank publishes "my launch has landed" behind its
- * kernel, the root's stream waits for all of them — two one-wave kernels on `shared_flags`: ONE page-aligned 4 KiB page
- * of host memory shared by all ranks (POSIX shm, or a MAP_SHARED mapping made before fork), zeroed by whoever creates
- * it. (hipStreamWaitValue32 cannot do this: it accepts only the calling process's signal memory.) Back-pressure: a
- * rank's next launch waits until the root has begun ITS next launch, which it enqueues behind whatever consumed the batch
- * on its stream. Device buffers only; bind_outputs is refused while it is active; drone_vec_gather_close gives the handle
- * its own output buffers back. A dead peer: every wait gives up after DRONE_PEER_TIMEOUT_MS (default 10 000) — the
- * stream-side ones set a flag that fails the next call on the handle; DRONE_PEER_HOST_WAIT=1 moves the whole handshake
- * to the host (the stream is drained, the host polls / stores), where the timeout is an immediate error. */
+ * handshake, one call per launch on every rank as with RCCL, through `shared_flags`: ONE page-aligned 4 KiB page of host
+ * memory shared by all ranks (POSIX shm, or a MAP_SHARED mapping made before fork), zeroed by whoever creates it.
+ * (hipStreamWaitValue32 cannot do this: it accepts only the calling process's signal memory.) Round 5: the two
+ * publications ride on the launches that write the outputs — a non-root rank's reset / step / rollout kernel says "my
+ * launch has landed" itself (every workgroup releases its stores system-wide, the last one to finish stores the flag) and
+ * the root's next launch acknowledges the previous round from its first workgroup — so what is left as launches of their
+ * own are the two WAITS, one bounded one-wave kernel each: the root's stream waits for all ranks' flags, a non-root
+ * rank's next launch waits until the root has begun ITS next launch (back-pressure: the root enqueues that launch behind
+ * whatever consumed the batch on its stream). DRONE_PEER_INKERNEL=0 keeps the publications as one-wave launches (round 4).
+ * Device buffers only. While the exchange is active these fail with a message: drone_vec_bind_outputs (the exchange owns
+ * the output bindings), drone_vec_step_many / step_repeat (they write the caller's blocks, outside the handshake) and
+ * drone_vec_enable_graph_capture — and drone_vec_gather_init_peer itself on a handle already in graph-safe mode: the
+ * handshake's round numbers are host state baked into each launch, so a replayed capture would wait for and publish a
+ * stale round. drone_vec_gather_close gives the handle its own output buffers back and forgets the export (export again
+ * before another drone_vec_gather_init_peer). A dead peer: every wait gives up after DRONE_PEER_TIMEOUT_MS (default
+ * 10 000; clamped to 1 ... 600 000, anything else is the default) — a stream-side wait raises a flag that fails the next
+ * call on the handle and makes every wait already queued behind it return at once; DRONE_PEER_HOST_WAIT=1 moves the whole
+ * handshake to the host (the stream is drained, the host polls / stores), where the timeout is an immediate error. */
 #define DRONE_PEER_TOKEN_BYTES 288
 int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* all_rewards,
                                  unsigned char* all_terminals, unsigned char* all_truncations, unsigned char* token);

@@ -32,8 +32,14 @@ def test_bench_line_has_the_contract_fields(hip):
     # profiler was not usable; either way within a few per cent of the algorithmic bytes
     assert rf["traffic_measured_in_this_run"] in (True, False) and rf["traffic"] > 0 and rf["traffic"] == rf["traffic_detail"]["hbm_bytes_per_launch"]  # the contract's number: bytes per launch
     assert 0.97 < rf["traffic_over_algorithmic"] < 1.05, rf["traffic_detail"]
-    if rf["traffic_measured_in_this_run"]:  # rocprofv3's own kernel durations on this box agree with the HIP events' launch average
-        assert rf["frac_from_rocprof_kernel_avg"] == pytest.approx(rf["frac"], rel=0.08), (rf["frac_from_rocprof_kernel_avg"], rf["frac"])
+    if rf["traffic_measured_in_this_run"]:
+        # rocprofv3's kernel durations against HIP events over the SAME launches (the profiled child's own line): the tight check
+        # (events see the ~1 us between launches too). Against THIS process's events only loosely: two processes on one box place
+        # their 1.1 GB differently and time this HBM-bound kernel up to 10 % apart (0.746 against 0.825 in one run of round 5;
+        # profiles/README.md) — and each now picks its own sweep order at its first reset.
+        td = rf["traffic_detail"]
+        assert td["rocprof_kernel_avg_us"] == pytest.approx(td["same_process_hip_event_launch_us"], rel=0.03), td
+        assert rf["frac_from_rocprof_kernel_avg"] == pytest.approx(rf["frac"], rel=0.15), (rf["frac_from_rocprof_kernel_avg"], rf["frac"])
     assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes_per_env_step"] * rf["envs"] / (rf["launch_us"] * 1e-6) / 1e9)
     assert rf["frac_2pow22"] == rf["frac"] and rf["frac_of_measured_copy_peak"] == pytest.approx(rf["achieved"] / 6290.0)
     pts = rf["beyond_infinity_cache"]
@@ -45,9 +51,18 @@ def test_bench_line_has_the_contract_fields(hip):
     am = rf["at_metric_size"]
     assert am["envs"] == 65536 and am["frac_incl_infinity_cache"] == rf["frac_incl_infinity_cache"] == pytest.approx(am["achieved"] / 8000.0)
     assert am["achieved"] * 1e9 == pytest.approx(d["value"] * am["algorithmic_bytes_per_env_step"], rel=0.3)
+    # round 5: the timed window is steady state and says so — a fixed untimed pre-roll ahead of --warmup, the episodes that ended
+    # inside the timed launches (vec_log deltas), the working set from the handle's own byte count
+    assert d["pre_roll_steps"] == 150 and d["episodes_in_timed_window"] > 0
+    assert d["episode_ends_per_env_step"] == pytest.approx(d["episodes_in_timed_window"] / (65536 * 400)) and 0.002 < d["episode_ends_per_env_step"] < 0.02
+    assert am["working_set_bytes_per_step"] == am["algorithmic_bytes_per_env_step"] * 65536 and "285 MB" not in am["note"]
+    sm131 = d["configs"]["configs[2]/shard"]["step_many"]["K8"]
+    assert sm131["timed_stream_ms"] >= 15.0 and sm131["warmup_launches"] >= 30 and sm131["timed_launches"] >= 64
     # which kernel instantiation every timed handle ran
     assert set(d["variants"]) >= {"hover:65536", "hover:4194304", "hover:1024", "hover:131072", "waypoint:262144"}
-    assert "mem=2,dt=1" in d["variants"]["hover:4194304"] and "order=8" in d["variants"]["hover:4194304"] and "dt=0" in d["variants"]["hover:65536"]
+    big = d["variants"]["hover:4194304"]  # beyond 400 MiB per step the sweep order is measured at the first reset (round 5): one of the tested set, and it says what it tried
+    assert "dt=1" in big and "autotuned=1" in big and "table=8" in big and any(f" order={o} " in big for o in (0, 6, 8)) and "tried=o8:" in big and "dt=0" in d["variants"]["hover:65536"]
+    assert "autotuned" not in d["variants"]["hover:65536"] and "autotuned" not in d["variants"]["hover:131072"]
     # round 3: every other single-GPU BASELINE workload timed in the same run, each with its own bytes
     cf = d["configs"]
     assert set(cf) == {"configs[0]", "configs[1]", "configs[2]/shard", "configs[3]"}
@@ -185,3 +200,42 @@ def test_a_rank_lost_in_an_optional_record_cannot_cost_the_line(hip, fault, how,
     d = check_two_rank_line(r, optional_ok=False)
     assert how in d["optional"], d["optional"]
     assert d["value"] > 0 and d["secondary_values"]["no_gather"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_eight_ranks_oversubscribed_at_the_metrics_shape(hip):
+    """the driver's own multi-GPU command — `python bench.py --gpus 8 --steps 20 --warmup 5`, 2^20 envs
+    as eight shards of 131 072 — rehearsed on the ONE GPU there is (eight ranks over gloo): every rank-count-dependent path
+    of the line (shard offsets, the n1_same_box handle beside rank 0's shard, eight-way gathers, the optional child job's
+    budget, the C host with eight processes) runs before an 8-GPU node ever sees it. Not a measurement (`warning` says so);
+    what is checked is that the line arrives, complete, well inside the driver's patience."""
+    import time
+
+    env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=900, env=env)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    assert last.startswith("{"), "the JSON line must be the LAST line on stdout"
+    d = json.loads(last)
+    print(f"bench.py --gpus 8 oversubscribed on one GPU: {wall:.0f} s wall, optional: {d.get('optional')}")
+    assert wall < 600, f"{wall:.0f} s"
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 20 and d["warmup"] == 5
+    assert d["value_from"] == "gather_step" and d["value"] == d["records"]["gather_step"]["env_steps_per_s"] > 0
+    assert d["config"]["envs_per_gpu"] == 131072 and "1048576 envs in total" in d["config"]["workload"]
+    n1 = d["records"]["n1_same_box"]
+    assert n1["envs"] == 1 << 20 and n1["per_step"]["env_steps_per_s"] > 0 and n1["rollout"]["env_steps_per_s"] > 0
+    assert CORE <= set(d["records"])
+    assert "timed out" not in d["optional"] and d["optional"].startswith("ok"), d["optional"]
+    assert OPTIONAL <= set(d["records"]), OPTIONAL - set(d["records"])
+    for name in CORE | OPTIONAL:
+        if name != "n1_same_box":
+            assert d["records"][name].get("env_steps_per_s", 0) > 0, (name, d["records"][name])
+    assert d["records"]["gather_peer_store"]["env_steps_per_launch_per_gpu"] == 131072
+    assert d["records"]["rollout_gather"]["horizon"] == 128 and d["records"]["rollout_gather_peer_store"]["env_steps_per_launch_per_gpu"] == 131072 * 128
+    ch = d["records"]["c_host_mp"]
+    assert ch["per_step"]["gpus"] == 8 and ch["per_step"]["envs"] == 1 << 20 and ch["rollout"]["env_steps_per_s"] > 0
+    assert "warning" in d and d["roofline"]["envs"] == 131072
+    assert 0 < d["job_wall_s"] <= wall  # the line's own account of how long rank 0's job took (DESIGN.md quotes it)

@@ -71,6 +71,21 @@ def test_checkpoint_restores_the_buffers_and_refuses_another_env(hip, tmp_path):
         hip.DroneVec(n, seed=1, task=1, device="cuda:0", horizon=77).load_checkpoint(path)
     with pytest.raises(ValueError, match="task"):
         hip.DroneVec(n, seed=1, task=0, device="cuda:0").load_checkpoint(path)
+    # a file from another SPEC version (or from before the field existed: SPEC v4 and earlier) means other log sums and
+    # reset draws: refused rather than continued
+    with np.load(path) as z:
+        fields = {k: z[k] for k in z.files}
+    assert int(fields["spec_version"]) == hip.DroneVec.SPEC_VERSION == 5
+    for name, drop in (("old.npz", True), ("other.npz", False)):
+        alt = dict(fields)
+        if drop:
+            del alt["spec_version"]
+        else:
+            alt["spec_version"] = np.int64(4)
+        with open(str(tmp_path / name), "wb") as fh:
+            np.savez(fh, **alt)
+        with pytest.raises(ValueError, match="SPEC v4"):
+            b.load_checkpoint(str(tmp_path / name))
 
 
 @pytest.mark.gpu

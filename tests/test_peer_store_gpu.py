@@ -75,7 +75,7 @@ v.close()
 """
 
 
-def run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env=None, skip_ranks=()):
+def run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env=None, skip_ranks=(), timeout=120):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
     tokfile, out = str(tmp_path / "token"), str(tmp_path / "out.npz")
@@ -88,7 +88,7 @@ def run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_en
     res = {}
     try:
         for r, p in procs.items():
-            so, se = p.communicate(timeout=120)
+            so, se = p.communicate(timeout=timeout)
             res[r] = (p.returncode, se)
     finally:
         for p in procs.values():
@@ -99,21 +99,32 @@ def run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_en
 
 
 @pytest.mark.parametrize("world,total,task,root,rollout,host_wait", [(2, 8192, 0, 0, 0, 0), (3, 7001, 1, 2, 0, 0), (2, 4096, 2, 1, 0, 0), (3, 6001, 3, 0, 16, 0),
-                                                                    (2, 5000, 0, 0, 0, 1), (3, 9000, 0, 1, 0, 2), (2, 5000, 1, 0, 0, 3)])
+                                                                    (2, 5000, 0, 0, 0, 1), (3, 9000, 0, 1, 0, 2), (2, 5000, 1, 0, 0, 3),
+                                                                    (3, 7001, 0, 1, 0, 4), (3, 6001, 3, 2, 16, 4), (3, 9000, 0, 0, 0, 5), (2, 5000, 0, 1, 0, 6), (2, 5000, 0, 0, 0, 7),
+                                                                    # configs[2] / configs[4] at their real shape: eight processes x 131 072 envs
+                                                                    (8, 1 << 20, 0, 0, 0, 0), (8, (1 << 20) + 5, 0, 3, 0, 0), (8, 1 << 20, 0, 7, 128, 0), (8, 1 << 20, 0, 0, 0, 2)])
 def test_peer_stores_land_every_ranks_rows_in_the_roots_batch(oracle, hip, tmp_path, world, total, task, root, rollout, host_wait):
-    """host_wait: 0 stream-side handshake, 1 host-side; 2 / 3: the same two with a SLOW consumer on the root (it sleeps
-    before reading the batch): the other ranks finish their round at once and must NOT overwrite their rows with the next
-    one until the root has begun its own next launch — the back-pressure half of the handshake."""
-    steps, seed = 48, 23
-    extra = {"DRONE_PEER_HOST_WAIT": "1"} if host_wait in (1, 3) else {}
-    if host_wait >= 2:
+    """host_wait: 0 stream-side handshake (round 5: the publications ride on the output-writing launches), 1 host-side; 2 / 3:
+    the same two with a SLOW consumer on the root (it sleeps before reading the batch): the other ranks finish their round at
+    once and must NOT overwrite their rows with the next one until the root has begun its own next launch — the back-pressure
+    half of the handshake. 4: round 4's form, the publications as one-wave launches of their own (DRONE_PEER_INKERNEL=0);
+    5: that form with a slow root. 6 / 7: DRONE_PEER_TIMEOUT_MS = 0 / -5 (stream-side / host-side): malformed budgets are the
+    default, not "give up at once" or "never" (ADVICE r4)."""
+    big = total > 200000
+    steps, seed = (40 if big else 48), 23
+    extra = {"DRONE_PEER_HOST_WAIT": "1"} if host_wait in (1, 3, 7) else {}
+    if host_wait in (2, 3, 5):
         extra["SLOW_ROOT"] = "1"
-    res, out = run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env=extra or None)
+    if host_wait in (4, 5):
+        extra["DRONE_PEER_INKERNEL"] = "0"
+    if host_wait in (6, 7):
+        extra["DRONE_PEER_TIMEOUT_MS"] = "0" if host_wait == 6 else "-5"
+    res, out = run_ranks(tmp_path, world, total, task, steps, seed, root, rollout, extra_env=extra or None, timeout=400 if big else 120)
     assert all(rc == 0 for rc, _ in res.values()), "\n".join(f"--- rank {r}: rc {rc}\n{se[-1500:]}" for r, (rc, se) in res.items())
     over = dict(horizon=20)
     if task == 2:
         over.update(agents_per_env=8, collision_radius=0.5)
-    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, **over), threads=4)
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, **over), threads=(os.cpu_count() or 4) if big else 4)
     o.reset(seed)
     crc = 0
     for buf in (o.observations, o.rewards, o.terminals, o.truncations):
@@ -146,24 +157,26 @@ def test_a_dead_peer_is_an_error_not_a_hang(hip, tmp_path, host_wait):
 EXE_MP = os.path.join(ROOT, "host", "drone_host_mp")
 
 
-@pytest.mark.parametrize("ranks,envs,task,rollout,root", [(2, 6000, 0, 0, 0), (3, 10001, 1, 0, 2), (3, 6144, 2, 16, 1), (2, 4097, 3, 0, 1)])
+@pytest.mark.parametrize("ranks,envs,task,rollout,root", [(2, 6000, 0, 0, 0), (3, 10001, 1, 0, 2), (3, 6144, 2, 16, 1), (2, 4097, 3, 0, 1),
+                                                          (8, 1 << 20, 0, 0, 0), (8, (1 << 20) + 5, 0, 128, 4)])  # the real shape of configs[2] / configs[4]
 def test_plain_c_host_peer_store_exchange(oracle, hip, ranks, envs, task, rollout, root):
     """host/drone_host_mp --exchange peer: the same exchange from plain C (north-star: "host side stays C calling HIP
     through a thin C-ABI") — fork before HIP, the root's export and the flag page through shared mappings made before the
     fork, device memory through drone_device_malloc, no HIP or RCCL header in the host. The root copies every batch to
     the host and chains a CRC-32 over it, which must equal ONE oracle run over all envs."""
-    steps, seed = 48, 31
+    big = envs > 200000
+    steps, seed = (256 if rollout else 40) if big else 48, 31
     cmd = [EXE_MP, "--gpus", str(ranks), "--envs", str(envs), "--steps", str(steps), "--task", str(task), "--seed", str(seed),
-           "--crc", "1", "--share-devices", "1", "--exchange", "peer", "--root", str(root), "--timeout", "120"]
+           "--crc", "1", "--share-devices", "1", "--exchange", "peer", "--root", str(root), "--timeout", "280" if big else "120"]
     if rollout:
         cmd += ["--rollout", str(rollout)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr + r.stdout
     import json
 
     got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert got["root"] == root and "peer-store" in got["mode"]
-    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=4)
+    assert got["root"] == root and "peer-store" in got["mode"] and got["gpus"] == ranks
+    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=(os.cpu_count() or 4) if big else 4)
     o.reset(seed)
     crc = zlib.crc32(o.observations.tobytes())
     launches = steps if not rollout else (steps + rollout - 1) // rollout
@@ -216,7 +229,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,total,task,root", [(2, 6000, 0, 0), (3, 7003, 1, 1)])
+@pytest.mark.parametrize("world,total,task,root", [(2, 6000, 0, 0), (3, 7003, 1, 1), (8, 1 << 20, 0, 0)])
 def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, world, total, task, root):
     """drone_amd.dist.PeerStoreGather: the same exchange behind the helper torch consumers (and bench.py) use — the token and
     the flag page's name cross torch.distributed (gloo here) once, in its constructor."""
@@ -230,14 +243,14 @@ def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, wor
     errs = []
     try:
         for p in procs:
-            so, se = p.communicate(timeout=180)
+            so, se = p.communicate(timeout=400)
             errs.append((p.returncode, se))
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
     assert all(rc == 0 for rc, _ in errs), "\n".join(f"--- rc {rc}\n{se[-1500:]}" for rc, se in errs)
-    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=4)
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=os.cpu_count() or 4)
     o.reset(seed)
     crc = 0
     for buf in (o.observations, o.rewards, o.terminals, o.truncations):
@@ -248,3 +261,100 @@ def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, wor
         for buf in (o.observations, o.rewards, o.terminals, o.truncations):
             crc = zlib.crc32(buf.tobytes(), crc)
     assert int(np.load(out)["crc"]) == crc
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("drone_peer_flags_")], "the flag page's name must be gone once every rank has mapped it"
+
+
+def test_paths_the_handshake_cannot_cover_are_refused(hip):
+    """graph-safe stepping and the K-steps-per-launch calls run outside the handshake (its round numbers are host
+    state baked into each launch; step_many writes the caller's blocks, not the root's rows). One process, world 1: the
+    refusals are local decisions. Each must fail with a message and leave the exchange usable."""
+    import torch
+
+    n = 4096
+    flags = np.zeros(2048, dtype=np.uint32)
+    page = flags[(-flags.ctypes.data % 4096) // 4:][:1024]  # a page-aligned 4 KiB window
+    assert page.ctypes.data % 4096 == 0
+
+    def glob(od):
+        return (torch.zeros((n, od), dtype=torch.float32, device="cuda:0"), torch.zeros(n, dtype=torch.float32, device="cuda:0"),
+                torch.zeros(n, dtype=torch.uint8, device="cuda:0"), torch.zeros(n, dtype=torch.uint8, device="cuda:0"))
+
+    v = hip.DroneVec(n, seed=3, task=0, device="cuda:0")
+    g = glob(20)
+    tok = v.gather_peer_export(*g)
+    v.gather_init_peer(tok, page, 0, 1, root=0)
+    v.reset(3); v.gather()
+    with pytest.raises(RuntimeError, match="peer-store"):
+        v.enable_graph_capture(True)
+    v.clear_status()
+    bufs = v.alloc_step_many(4)
+    with pytest.raises(RuntimeError, match="peer-store"):
+        v.step_many(bufs)
+    v.clear_status()
+    v.fill_random_actions(); v.step(); v.gather()   # still works, and lands in the exported batch
+    torch.cuda.synchronize()
+    assert float(g[0].abs().sum()) > 0 and v.status()[0] == 0
+    v.gather_close()
+    with pytest.raises(RuntimeError, match="export"):   # the export was consumed by the closed exchange
+        v.gather_init_peer(tok, page, 0, 1, root=0)
+    v.clear_status()
+    v.close()
+    # ... and the other way round: a handle already in graph-safe mode cannot start the exchange
+    v = hip.DroneVec(n, seed=3, task=0, device="cuda:0")
+    v.enable_graph_capture(True)
+    g = glob(20)
+    tok = v.gather_peer_export(*g)
+    with pytest.raises(RuntimeError, match="graph-safe"):
+        v.gather_init_peer(tok, page, 0, 1, root=0)
+    v.close()
+
+
+_WORKER_QUEUED = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from drone_amd import binding
+flagfile = sys.argv[1]
+v = binding.DroneVec(8192, seed=1, cfg=binding.default_config(0), device="cuda:0")
+flags = np.memmap(flagfile, dtype=np.uint32, mode="r+", shape=(1024,))
+g = (torch.zeros((16384, 20), dtype=torch.float32, device="cuda:0"), torch.zeros(16384, dtype=torch.float32, device="cuda:0"),
+     torch.zeros(16384, dtype=torch.uint8, device="cuda:0"), torch.zeros(16384, dtype=torch.uint8, device="cuda:0"))
+v.gather_init_peer(v.gather_peer_export(*g), flags, 0, 2, root=0)   # rank 1 never comes
+t0 = time.time()
+failed_at = None
+for k in range(40):   # a caller that does not sync every launch: every round's wait is queued behind the first one
+    try:
+        if k == 0: v.reset(1)
+        else: v.step()
+        v.gather()
+    except RuntimeError as exc:
+        failed_at = (k, str(exc)); break
+torch.cuda.synchronize()
+print("QUEUED", failed_at, round(time.time() - t0, 2), flush=True)
+try:
+    v.step()
+    print("NOERROR", flush=True)
+except RuntimeError as exc:
+    print("ERROR", str(exc)[:200], flush=True)
+print("ELAPSED", round(time.time() - t0, 2), flush=True)
+"""
+
+
+def test_waits_queued_behind_a_dead_peers_timeout_return_at_once(hip, tmp_path):
+    """with the handshake on the stream a caller may have enqueued many rounds before the first wait gives up
+    (DRONE_PEER_TIMEOUT_MS); each later wait must see the raised error word and return at once instead of spinning its own
+    budget: 40 rounds x 1.5 s would be a minute, the whole run must end within a few seconds of ONE budget."""
+    script = tmp_path / "worker_q.py"
+    script.write_text(_WORKER_QUEUED.format(root=ROOT))
+    flagfile = f"/dev/shm/drone_peer_flags_q_{os.getpid()}"
+    with open(flagfile, "wb") as fh:
+        fh.write(b"\0" * 4096)
+    try:
+        r = subprocess.run([sys.executable, str(script), flagfile], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DRONE_PEER_TIMEOUT_MS="1500"))
+    finally:
+        os.unlink(flagfile)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.split(" ", 1)[0] in ("QUEUED", "ERROR", "NOERROR", "ELAPSED"))
+    assert "ERROR" in lines and "gave up" in lines["ERROR"], r.stdout
+    assert float(lines["ELAPSED"]) < 12.0, f"queued waits spun their budgets one after the other: {r.stdout}"

@@ -228,6 +228,57 @@ def test_sweep_orders_are_bijective(oracle, hip, monkeypatch, order, n):
     assert_state_equal(o.get_state(), h.get_state(), f"order {order} state after rollout")
 
 
+def test_autotuned_sweep_leaves_no_trace_but_its_name(hip, monkeypatch):
+    """Round 5: a handle whose step touches more than 400 MiB measures its sweep order at the first reset —
+    on its own planes and buffers, with trial steps the reset that follows must erase completely. The handle says what it tried
+    (drone_vec_variant); DRONE_AUTOTUNE=0 keeps the footprint table's pick and says nothing; a forced order is not second-guessed;
+    both handles then walk the same trajectory, outputs and done lists included, and a SECOND reset does not tune again."""
+    import zlib
+
+    from helpers import to_np
+
+    n, seed = (1 << 21) + 300, 11  # 2.1 M hover envs (derived-target layout): 524 MiB per step, ragged last workgroup
+
+    def run(h):
+        h.reset(seed)
+        first_obs = zlib.crc32(to_np(h.observations).tobytes())
+        assert not to_np(h.terminals).any() and not to_np(h.rewards).any() and h.gstep == 0 and len(h.done_list()) == 0
+        for _ in range(30):
+            h.fill_random_actions()
+            h.step()
+        st = h.get_state()
+        out = [zlib.crc32(np.ascontiguousarray(st[f]).tobytes()) for f in st.dtype.names]
+        out += [zlib.crc32(to_np(x).tobytes()) for x in (h.observations, h.rewards, h.terminals, h.truncations)]
+        return first_obs, out, np.sort(h.done_list())
+
+    h = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
+    before, _ = h.variant
+    assert "autotuned" not in before  # nothing measured yet: the table's candidate
+    a = run(h)
+    text, var = h.variant
+    assert var["autotuned"] == 1 and var["order"] in (0, 6, 8) and var["table"] in (0, 6, 8) and var["mem"] == (var["order"] >> 2) & 3, text
+    tried = dict(kv.split(":") for kv in text.split("tried=")[1].split()[0].split(","))
+    assert set(tried) == {"o0", "o6", "o8"} and all(20.0 < float(us) < 2000.0 for us in tried.values()), text
+    assert float(tried[f"o{var['order']}"]) == min(float(us) for us in tried.values())
+    again = run(h)  # a second reset: same trajectory, no second measurement
+    assert h.variant[0] == text and again[0] == a[0] and again[1] == a[1] and np.array_equal(again[2], a[2])
+    h.close()
+    monkeypatch.setenv("DRONE_AUTOTUNE", "0")
+    h0 = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
+    b = run(h0)
+    assert "autotuned" not in h0.variant[0] and h0.variant[1]["order"] == var["table"]
+    h0.close()
+    monkeypatch.delenv("DRONE_AUTOTUNE")
+    monkeypatch.setenv("DRONE_SWEEP_ORDER", "2")
+    h2 = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
+    c = run(h2)
+    assert "autotuned" not in h2.variant[0] and h2.variant[1]["order"] == 2
+    h2.close()
+    for other, name in ((b, "DRONE_AUTOTUNE=0"), (c, "forced order 2")):
+        assert other[0] == a[0], f"{name}: observations right after the reset differ: a trial step survived it"
+        assert other[1] == a[1] and np.array_equal(other[2], a[2]), f"{name}: trajectories differ from the autotuned handle's"
+
+
 @pytest.mark.parametrize("task", [0, 1, 3])
 def test_state_rows_on_unaligned_subranges(hip, task):
     """get_state / set_state address the tiled layout ([tile of 64][plane][lane]): ranges that start and end inside a
@@ -332,7 +383,7 @@ def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip, monkeypatch):
     cases = [("binding's own page buffers", None, "zero-copy", None, "mirror"),
              ("caller's heap arrays (np.zeros): share pages with other allocations", mk(heap), "stand-in", None, "stand-in"),
              ("the same with stand-ins turned off", mk(heap), "mirror", "0", "mirror"),
-             ("the same with a stand-in budget below this shard's 408 KiB", mk(heap), "mirror", "300000", "mirror"),
+             ("the same with a single-memcpy budget below this shard's 408 KiB: the host copy pool moves the stand-ins (round 5)", mk(heap), "stand-in-mt", "300000", "stand-in-mt"),
              ("a PufferLib-style worker: page-owning observations / actions / rewards, heap flag slices",
               (hip.page_buffer((n, 20), np.float32), hip.page_buffer((n, 4), np.float32), hip.page_buffer((n,), np.float32), np.zeros(n + 64, np.uint8)[64:], np.zeros(n + 64, np.uint8)[64:]),
               "stand-in", None, "mirror"),  # its action buffer was mapped directly: replacing it ends the zero-copy transport
@@ -374,11 +425,19 @@ def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip, monkeypatch):
     h = hip.DroneVec(m, seed=seed, cfg=hip.default_config(0), buffers=(base, np.zeros((m, 4), np.float32), np.zeros(m, np.float32), np.zeros(m, np.uint8), np.zeros(m, np.uint8)))
     assert h.host_transport == "stand-in"  # nothing of the caller's was registered
     h.close()
-    # a shard whose unpinnable buffers exceed the stand-in budget takes the mirror transport
+    # a shard whose unpinnable buffers exceed the single-memcpy budget: stand-ins moved by the host copy pool (round 5);
+    # without a pool (DRONE_HOST_COPY_THREADS=1 is read when the pool starts: a process-wide choice, tested in
+    # tests/test_host_copy_pool_gpu.py in a process of its own) or beyond DRONE_HOST_MT_MAX_BYTES, the mirror transport
     big = 16384
-    h = hip.DroneVec(big, seed=seed, cfg=hip.default_config(0), buffers=(np.zeros((big, 20), np.float32), np.zeros((big, 4), np.float32), np.zeros(big, np.float32), np.zeros(big, np.uint8), np.zeros(big, np.uint8)))
+    mkbig = lambda: (np.zeros((big, 20), np.float32), np.zeros((big, 4), np.float32), np.zeros(big, np.float32), np.zeros(big, np.uint8), np.zeros(big, np.uint8))
+    h = hip.DroneVec(big, seed=seed, cfg=hip.default_config(0), buffers=mkbig())
+    assert h.host_transport == "stand-in-mt"
+    h.close()
+    monkeypatch.setenv("DRONE_HOST_MT_MAX_BYTES", "1500000")  # this shard has 1.7 MB of unpinnable buffers
+    h = hip.DroneVec(big, seed=seed, cfg=hip.default_config(0), buffers=mkbig())
     assert h.host_transport == "mirror"
     h.close()
+    monkeypatch.delenv("DRONE_HOST_MT_MAX_BYTES")
 
 
 def test_host_handles_beside_pageable_copies_do_not_fault(hip):

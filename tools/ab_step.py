@@ -46,7 +46,10 @@ def main():
         name, _, rest = spec.partition("=")
         flags, _, envs = rest.partition(";")
         lib = f"/tmp/ab_{abs(hash(flags)) % 10**8}.so"
-        if not os.path.exists(lib):
+        if flags.startswith("@"):  # a library built elsewhere (e.g. last round's sources: tools/ab_libs/), relative to the repo root
+            lib = os.path.join(ROOT, flags[1:])
+            assert os.path.exists(lib), lib
+        elif not os.path.exists(lib):
             r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "drone_amd", "csrc"), "-B", f"OUT={lib}", f"EXTRA={flags}"],
                                capture_output=True, text=True)
             if r.returncode != 0:
