@@ -114,8 +114,8 @@
 #ifndef DRONE_CARRY_ROTOR  // 1: the register-resident kernels carry the rotor inputs from step to step (Lane::u); 0: recompute them every step (A/B only)
 #define DRONE_CARRY_ROTOR 1
 #endif
-#ifndef DRONE_PRIO_ROTATE  // 1: the register-resident kernels rotate s_setprio among the waves that share a SIMD (PrioRotor below); 0: the hardware's oldest-first arbitration (A/B)
-#define DRONE_PRIO_ROTATE 1
+#ifndef DRONE_PRIO_ROTATE  // 1: the register-resident kernels rotate s_setprio among the waves that share a SIMD (PrioRotor below); 0 (default): the hardware's oldest-first arbitration. Measured (round 5, profiles/r05_ab/ab_prio_rollout_*.txt): the rotation does level the waves of a SIMD (they end 132 / 148 us after the start at 131 072 envs instead of 110 / 152) but the SIMD retires less while priorities differ (one VALU per 3.3 cycles against 2.83): -2 % at 131 072 envs, +1 % at 262 144, 0 at 2^20, and a period of 32 steps swings from -5 % to +9 % between sizes. Negative result: off
+#define DRONE_PRIO_ROTATE 0
 #endif
 #ifndef DRONE_PRIO_ROTATE_MANY  // the same in the K-steps-per-launch kernel. Off: that kernel has no scalar register to spare (the one word of state costs the swarm / waypoint instantiations 100-180 v_readlane / v_writelane spills)
 #define DRONE_PRIO_ROTATE_MANY 0
@@ -934,12 +934,14 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
 #endif
     PrioRotor prio;
     prio.init(prio_mod);
+    KParams Pv = P;  // the step loop's view of the constants: the RK4's sixteen in vector registers (drone_lane.hpp, rk4_consts_to_vgprs)
+    if (!PK) rk4_consts_to_vgprs(Pv);
     for (uint32_t t = 0; t < horizon; t++) {
         prio.tick(t, (1u << DRONE_PRIO_PERIOD_LOG2) - 1u);
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, true, (DRONE_SCALAR_RESET != 0) && !PK>(P, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, true, (DRONE_SCALAR_RESET != 0) && !PK>(Pv, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
@@ -1108,7 +1110,9 @@ __global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m)
     L.u = rotor_inputs(P, L.s.r);  // carried through the K steps (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     bool any_target = false, any_end = false;
-    if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true, PK>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
+    KParams Pv = P;  // the RK4's sixteen constants in vector registers (drone_lane.hpp, rk4_consts_to_vgprs): full-rate encodings once waves share a SIMD
+    if (!PK) rk4_consts_to_vgprs(Pv);
+    if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true, PK>(Pv, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
     else many_loop<TASK, COMPACT, POLICY, false, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard (one workgroup: scalar form, less code)
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
     store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)), dt);

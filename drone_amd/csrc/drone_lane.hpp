@@ -335,6 +335,35 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
     u0 = uf;
 }
 
+// Round 5. On gfx950 a VOP3-encoded VALU instruction that reads a SCALAR register (v_fma_f32 v, s, v, v — how every
+// "state + h * derivative" update and every damping / gyroscopic term below is encoded while the constants sit in SGPRs) is
+// a HALF-rate instruction as soon as several waves compete for the SIMD: two waves of it retire one instruction per 2.75
+// cycles instead of 2.06, four waves one per 4.2 instead of 2.2; the VOP2 forms (v_mul_f32_e32 v, s, v; v_fmac_f32_e32) and
+// every all-VGPR form run at the full rate (tools/micro/valu_pairs.hip, profiles/r05_ab/valu_pairs.txt). 78 of the 275
+// instructions of a scalar RK4 substep are of that kind, fed by 16 constants. The register-resident kernels therefore copy
+// those 16 into VECTOR registers once, ahead of their step loop: same values, same instructions, other operand class —
+// bit-identical by construction. (The packed form takes its constants as SGPR pairs by design and is left alone: it runs
+// where a SIMD holds one wave, and a lone wave issues every instruction class at the same rate.)
+#ifndef DRONE_RK4_VGPR_CONSTS
+#define DRONE_RK4_VGPR_CONSTS 1
+#endif
+DRONE_FN float vgpr_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));  // opaque to the optimiser from here on: it can no longer prove the value uniform, so it stays in a VGPR
+#endif
+    return x;
+}
+DRONE_FN void rk4_consts_to_vgprs(KParams& Q) {
+#if DRONE_RK4_VGPR_CONSTS
+    Q.h = vgpr_(Q.h); Q.h_half = vgpr_(Q.h_half); Q.h_sixth = vgpr_(Q.h_sixth);
+    Q.hq = vgpr_(Q.hq); Q.hq_half = vgpr_(Q.hq_half); Q.hq_sixth = vgpr_(Q.hq_sixth);
+    Q.gxi = vgpr_(Q.gxi); Q.gyi = vgpr_(Q.gyi); Q.gzi = vgpr_(Q.gzi);
+    Q.kdx = vgpr_(Q.kdx); Q.kdy = vgpr_(Q.kdy); Q.kdz = vgpr_(Q.kdz);
+    Q.drag_m = vgpr_(Q.drag_m); Q.gravity = vgpr_(Q.gravity);
+    Q.e_half = vgpr_(Q.e_half); Q.e_full = vgpr_(Q.e_full);
+#endif
+}
+
 // all substeps of one env step, in the form the caller picked
 template <int TASK, bool PK>
 DRONE_FN void rk4_run(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u) {

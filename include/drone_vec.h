@@ -132,7 +132,7 @@ const char* drone_vec_variant(const DroneVec* v);
  * DRONE_HOST_BOUNCE_MAX_BYTES, default 1 MiB of such buffers); 3 (round 5) = the same stand-ins for mid-size shards (up to
  * DRONE_HOST_MT_MAX_BYTES, default 64 MiB of unpinnable buffers — a vec-env worker's unaligned shared-memory slices at
  * 16 384 ... ~10^5 envs), moved by a small pool of host threads (DRONE_HOST_COPY_THREADS per job, caller included; default
- * 4, 1 = off): the action rows go in as parallel slices, and the outputs come out WHILE the step kernel is still writing
+ * half the machine's hardware threads, at most 8; 1 = off): the action rows go in as parallel slices, and the outputs come out WHILE the step kernel is still writing
  * over PCIe — each 256-drone chunk as soon as its workgroup says its rows have landed. The pool is one per process, started
  * on first use; its threads spin for ~200 us after a job and sleep otherwise; it serves one handle at a time (from
  * drone_vec_step_send to drone_vec_step_recv it belongs to that handle): a second handle stepped meanwhile does its own

@@ -1,9 +1,10 @@
-"""profiles/r04_*: what is committed as evidence must be one consistent set (VERDICT r3 item 2b — half of profiles/r03_*
-named a kernel that no longer existed). Every round-4 profile directory names the build it measured (git revision, sha256
+"""profiles/r05_*: what is committed as evidence must be one consistent set (VERDICT r3 item 2b — half of profiles/r03_*
+named a kernel that no longer existed; round 4's set, profiles/r04_*, stays as history: its summaries name the build it came
+from, whose fused-rollout kernel had one argument fewer). Every round-5 profile directory names the build it measured (git revision, sha256
 of the libdrone_hip.so that ran on the GPU box) and its kernels by demangled and mangled name; here, on the CPU:
   * the kernel rows of kernel_stats.csv and of summary.json are the same kernels;
   * every mangled name exists in the ISA listing of the CURRENT sources (a kernel renamed or re-templated after the
-    profile was taken makes the profile stale: re-run tools/r04_profiles.sh + tools/collect_r04.py);
+    profile was taken makes the profile stale: re-run tools/r05_profiles.sh + tools/collect_round.py r05);
   * all directories, traffic_latest.json and rollout_valu.json come from ONE build, taken from a clean tree;
   * the roofline fraction of the committed bench line is reproduced from the profile: algorithmic bytes x envs /
     rocprofv3's average kernel time / 8 TB/s."""
@@ -17,9 +18,10 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", "r04_*")) if os.path.isfile(os.path.join(d, "summary.json")))
+ROUND = "r05"
+DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", ROUND + "_*")) if os.path.isfile(os.path.join(d, "summary.json")))
 
-pytestmark = pytest.mark.skipif(not DIRS, reason="no round-4 profiles committed yet")
+pytestmark = pytest.mark.skipif(not DIRS, reason="no round-5 profiles committed yet (tools/r05_profiles.sh on the GPU box, tools/collect_round.py r05 here)")
 
 
 @pytest.fixture(scope="module")
@@ -53,14 +55,19 @@ def test_one_build_behind_everything():
     for key, t in traffic.items():
         assert (t["build"]["git_head"], t["build"]["so_sha256_on_the_gpu_box"]) == one, key
     assert one[0][:12] in json.load(open(os.path.join(ROOT, "profiles", "rollout_valu.json")))["hover"]["source"]
-    sq = json.load(open(os.path.join(ROOT, "profiles", "r04_rollout_hover", "sq_counters.json")))
-    assert (sq["build"]["git_head"], sq["build"]["so_sha256_on_the_gpu_box"]) == one
+    # the SQ counter passes of the fused rollout: the metric's size and the per-rank shards of configs[4]
+    for d in ("rollout_hover", "rollout_hover_131072", "rollout_hover_262144"):
+        sq = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_{d}", "sq_counters.json")))
+        assert (sq["build"]["git_head"], sq["build"]["so_sha256_on_the_gpu_box"]) == one, d
+        k = next(v for n, v in sq["counters"].items() if "rollout" in n)
+        assert {"SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"} <= set(k), d
+        assert 380 < k["SQ_INSTS_VALU"] / k["SQ_WAVES"] / 128.0 < 440, d  # VALU instructions per wave and env step
 
 
 def test_the_bench_lines_roofline_is_reproduced_by_the_profile():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_default.json")))
     rf = line["roofline"]
-    s = json.load(open(os.path.join(ROOT, "profiles", f"r04_step_hover_{rf['envs']}", "summary.json")))
+    s = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_step_hover_{rf['envs']}", "summary.json")))
     k = next(x for x in s["kernels"] if "drone_step_kernel" in x["name"])
     frac = rf["algorithmic_bytes_per_env_step"] * rf["envs"] / (k["avg_us"] * 1e-6) / 8e12
     # Two processes on one box, minutes apart, time this HBM-bound kernel up to 8 % apart (169 and 182 us in the committed
@@ -73,12 +80,19 @@ def test_the_bench_lines_roofline_is_reproduced_by_the_profile():
         assert rf["frac_from_rocprof_kernel_avg"] == pytest.approx(rf["frac"], rel=0.03), (rf["frac_from_rocprof_kernel_avg"], rf["frac"])
     # ... and the metric's size beside it
     am = rf["at_metric_size"]
-    s2 = json.load(open(os.path.join(ROOT, "profiles", "r04_step_hover", "summary.json")))
+    s2 = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_step_hover", "summary.json")))
     k2 = next(x for x in s2["kernels"] if "drone_step_kernel" in x["name"])
     assert am["algorithmic_bytes_per_env_step"] * am["envs"] / (k2["avg_us"] * 1e-6) / 8e12 == pytest.approx(am["frac"], rel=0.03)
     # the PMC traffic against the algorithmic bytes: no wasted re-reads
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[f"hover:{rf['envs']}"]
     assert 0.97 < t["hbm_bytes_per_launch"] / (rf["algorithmic_bytes_per_env_step"] * rf["envs"]) < 1.05
-    # the variant strings in the line are the instantiations the profile saw
-    assert "mem=2,dt=1" in line["variants"][f"hover:{rf['envs']}"] and "<0, false, 2, true>" in k["name"]  # task 0, no compaction, non-temporal state loads, derived-target layout
+    # the variant strings in the line are instantiations the parity suite covers; beyond 400 MiB per step each process measures its
+    # own sweep order at its first reset (round 5), so the bench process and the profiled one may have picked different ones
+    big = line["variants"][f"hover:{rf['envs']}"]
+    assert "dt=1" in big and "autotuned=1" in big and any(f" order={o} " in big for o in (0, 6, 8)) and "<0, false," in k["name"] and k["name"].rstrip(">").endswith("true")
     assert "mem=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, 0, true>" in k2["name"]
+    # the driver's 20-step window (--steps 20 --warmup 5 behind the 150-step pre-roll) describes the same kernel state as the
+    # profile: its ms_per_step within a few per cent of rocprofv3's average at the metric's size
+    drv = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_driver_window.json")))
+    assert drv["steps"] == 20 and drv["warmup"] == 5 and drv["pre_roll_steps"] == 150 and drv["episodes_in_timed_window"] > 0
+    assert drv["ms_per_step"] * 1e3 == pytest.approx(k2["avg_us"], rel=0.05), (drv["ms_per_step"] * 1e3, k2["avg_us"])

@@ -429,7 +429,8 @@ def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip, monkeypatch):
     # without a pool (DRONE_HOST_COPY_THREADS=1 is read when the pool starts: a process-wide choice, tested in
     # tests/test_host_copy_pool_gpu.py in a process of its own) or beyond DRONE_HOST_MT_MAX_BYTES, the mirror transport
     big = 16384
-    mkbig = lambda: (np.zeros((big, 20), np.float32), np.zeros((big, 4), np.float32), np.zeros(big, np.float32), np.zeros(big, np.uint8), np.zeros(big, np.uint8))
+    off = lambda shape, dt: np.zeros(int(np.prod(shape)) + 16, dt)[16:].reshape(shape)  # 16 elements into its block: on no page boundary, whatever the allocator did
+    mkbig = lambda: (off((big, 20), np.float32), off((big, 4), np.float32), off((big,), np.float32), off((big,), np.uint8), off((big,), np.uint8))
     h = hip.DroneVec(big, seed=seed, cfg=hip.default_config(0), buffers=mkbig())
     assert h.host_transport == "stand-in-mt"
     h.close()

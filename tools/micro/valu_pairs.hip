@@ -18,9 +18,9 @@
 #include <map>
 #include <vector>
 
-enum Class { FMA = 0, FMAC, MUL, ADD, MOV, XOR, LSHR, ADDU, MULLO, CVT, CNDMASK, CMP, MED3, FMA_SGPR, FMA_LIT, XOR_SDWA, FMA_2SGPR, MUL_SGPR, FMA_DEP, CND_SMASK, CMP_E64, MAX3, MULHI, MUL24, CVT_I, RCP, SQRT, BFE, LSHLADD, NCLASS };
+enum Class { FMA = 0, FMAC, MUL, ADD, MOV, XOR, LSHR, ADDU, MULLO, CVT, CNDMASK, CMP, MED3, FMA_SGPR, FMA_LIT, XOR_SDWA, FMA_2SGPR, MUL_SGPR, FMA_DEP, CND_SMASK, CMP_E64, MAX3, MULHI, MUL24, CVT_I, RCP, SQRT, BFE, LSHLADD, FMA_S0, FMA_S2, FMA_NEG, FMAC_S0, MUL64_S0, FMA_INL, FMA_NEGS0, NCLASS };
 static const char* kNames[NCLASS] = {"fma", "fmac_e32", "mul", "add", "mov", "xor", "lshr", "add_u32", "mul_lo_u32", "cvt_f32_u32", "cndmask", "cmp_lt",
-                                     "med3", "fma_sgpr", "mul_literal", "xor_sdwa", "fma_same_sgpr_x2", "mul_sgpr_e32", "fma_dependent", "cndmask_e64_smask", "cmp_e64_sdst", "max3", "mul_hi_u32", "mul_u32_u24", "cvt_f32_i32", "rcp", "sqrt", "bfe_u32", "lshl_add_u32"};
+                                     "med3", "fma_sgpr", "mul_literal", "xor_sdwa", "fma_same_sgpr_x2", "mul_sgpr_e32", "fma_dependent", "cndmask_e64_smask", "cmp_e64_sdst", "max3", "mul_hi_u32", "mul_u32_u24", "cvt_f32_i32", "rcp", "sqrt", "bfe_u32", "lshl_add_u32", "fma_sgpr_src0", "fma_sgpr_src2", "fma_neg_vgpr", "fmac_e32_sgpr_src0", "mul_e64_sgpr_src0", "fma_inline_2.0", "fma_neg_sgpr_src0"};
 
 #define R8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
 #define R128(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP) R8(OP)
@@ -59,6 +59,13 @@ static const char* kNames[NCLASS] = {"fma", "fmac_e32", "mul", "add", "mov", "xo
 #define I_SQRT(k) "v_sqrt_f32_e32 %" #k ", %" #k "\n"
 #define I_BFE(k) "v_bfe_u32 %" #k ", %" #k ", 3, 8\n"
 #define I_LSHLADD(k) "v_lshl_add_u32 %" #k ", %" #k ", 1, %8\n"
+#define I_FMAS0(k) "v_fma_f32 %" #k ", %10, %" #k ", %9\n"
+#define I_FMAS2(k) "v_fma_f32 %" #k ", %" #k ", %8, %10\n"
+#define I_FMANEG(k) "v_fma_f32 %" #k ", -%" #k ", %8, %9\n"
+#define I_FMACS0(k) "v_fmac_f32_e32 %" #k ", %10, %8\n"
+#define I_MUL64S0(k) "v_mul_f32_e64 %" #k ", %10, %" #k "\n"
+#define I_FMAINL(k) "v_fma_f32 %" #k ", %" #k ", 2.0, %9\n"
+#define I_FMANEGS0(k) "v_fma_f32 %" #k ", -%10, %" #k ", %9\n"
 
 __global__ __launch_bounds__(1024) void k(int clsA, int clsB, int iters, unsigned long long* stamps, float* sink, float fc1, float fc2) {
     const int wave = threadIdx.x >> 6;
@@ -108,6 +115,13 @@ __global__ __launch_bounds__(1024) void k(int clsA, int clsB, int iters, unsigne
         case SQRT: BODY(R128(I_SQRT)); break;
         case BFE: BODY(R128(I_BFE)); break;
         case LSHLADD: BODY(R128(I_LSHLADD)); break;
+        case FMA_S0: BODY(R128(I_FMAS0)); break;
+        case FMA_S2: BODY(R128(I_FMAS2)); break;
+        case FMA_NEG: BODY(R128(I_FMANEG)); break;
+        case FMAC_S0: BODY(R128(I_FMACS0)); break;
+        case MUL64_S0: BODY(R128(I_MUL64S0)); break;
+        case FMA_INL: BODY(R128(I_FMAINL)); break;
+        case FMA_NEGS0: BODY(R128(I_FMANEGS0)); break;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), q1 = __builtin_amdgcn_s_memrealtime();
     sink[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
