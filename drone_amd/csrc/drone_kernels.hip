@@ -934,7 +934,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
 #endif
     PrioRotor prio;
     prio.init(prio_mod);
-    KParams Pv = P;  // the step loop's view of the constants: the RK4's sixteen in vector registers (drone_lane.hpp, rk4_consts_to_vgprs)
+    KParams Pv = P;  // the step loop's view of the constants (with -DDRONE_RK4_VGPR_CONSTS=1: the RK4's sixteen in vector registers — drone_lane.hpp; measured a wash, off)
     if (!PK) rk4_consts_to_vgprs(Pv);
     for (uint32_t t = 0; t < horizon; t++) {
         prio.tick(t, (1u << DRONE_PRIO_PERIOD_LOG2) - 1u);
@@ -1110,7 +1110,7 @@ __global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m)
     L.u = rotor_inputs(P, L.s.r);  // carried through the K steps (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     bool any_target = false, any_end = false;
-    KParams Pv = P;  // the RK4's sixteen constants in vector registers (drone_lane.hpp, rk4_consts_to_vgprs): full-rate encodings once waves share a SIMD
+    KParams Pv = P;  // (with -DDRONE_RK4_VGPR_CONSTS=1: the RK4's sixteen constants in vector registers — drone_lane.hpp; measured a wash, off)
     if (!PK) rk4_consts_to_vgprs(Pv);
     if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true, PK>(Pv, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
     else many_loop<TASK, COMPACT, POLICY, false, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard (one workgroup: scalar form, less code)

@@ -335,17 +335,20 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
     u0 = uf;
 }
 
-// Round 5. On gfx950 a VOP3-encoded VALU instruction that reads a SCALAR register (v_fma_f32 v, s, v, v — how every
-// "state + h * derivative" update and every damping / gyroscopic term below is encoded while the constants sit in SGPRs) is
-// a HALF-rate instruction as soon as several waves compete for the SIMD: two waves of it retire one instruction per 2.75
-// cycles instead of 2.06, four waves one per 4.2 instead of 2.2; the VOP2 forms (v_mul_f32_e32 v, s, v; v_fmac_f32_e32) and
-// every all-VGPR form run at the full rate (tools/micro/valu_pairs.hip, profiles/r05_ab/valu_pairs.txt). 78 of the 275
-// instructions of a scalar RK4 substep are of that kind, fed by 16 constants. The register-resident kernels therefore copy
-// those 16 into VECTOR registers once, ahead of their step loop: same values, same instructions, other operand class —
-// bit-identical by construction. (The packed form takes its constants as SGPR pairs by design and is left alone: it runs
-// where a SIMD holds one wave, and a lone wave issues every instruction class at the same rate.)
+// Round 5, tried and not kept (the knob stays for the record). tools/micro/valu_pairs.hip: two waves of one SIMD that BOTH run
+// VOP3-encoded instructions with a scalar-register operand (v_fma_f32 v, s, v, v — how every "state + h * derivative" update and
+// every damping / gyroscopic term below is encoded while the constants sit in SGPRs) retire one instruction per 2.75 cycles
+// instead of 2.06, four waves one per 4.2 instead of 2.2; all-VGPR forms and the VOP2 forms with an SGPR in src0 run at the full
+// rate. 78 of the 275 instructions of a scalar RK4 substep are of that kind, fed by 16 constants. With DRONE_RK4_VGPR_CONSTS=1 the
+// register-resident kernels copy those 16 into VECTOR registers ahead of their step loop (same values, same instructions, other
+// operand class: bit-identical; the substep then holds no VOP3 + SGPR instruction at all). Measured, equal placement
+// (profiles/r05_ab/ab_vconst_*.txt): fused rollout -0.4 % at 2^20 envs, +0.9 % at 131 072, +1.3 % at 262 144; waypoint / race
+// +1.5 % / +0.6 % at 2^20 (136 / 138 VGPRs: a wave fewer per SIMD); step_many +-1 %. The conflict is between two waves that
+// issue such an instruction in the SAME window (the micro-benchmark's waves do nothing else); in a real stream one in five
+// instructions is of the kind and the partner's is usually not — the pair matrix of the same benchmark shows a restricted class
+// beside an unrestricted one co-issuing at the full rate. Not what holds the kernel at 2.5 cycles per instruction.
 #ifndef DRONE_RK4_VGPR_CONSTS
-#define DRONE_RK4_VGPR_CONSTS 1
+#define DRONE_RK4_VGPR_CONSTS 0
 #endif
 DRONE_FN float vgpr_(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)

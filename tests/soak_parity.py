@@ -53,7 +53,10 @@ def draw_case(rng, big=False):
             over[str(name)] = ("scale", float(rng.uniform(0.5, 2.0)))
     env = {"DRONE_DERIVED_TARGET": rng.choice(["", "0", "1"]), "DRONE_PACKED_RK4": rng.choice(["", "0", "1"]),
            "DRONE_LINE_COMPLETE": rng.choice(["", "0", "1"]), "DRONE_SWEEP_ORDER": rng.choice(["", "0", "1", "6", "8", "15"]),
-           "DRONE_HOST_ZEROCOPY": rng.choice(["", "0", "1"])}
+           "DRONE_HOST_ZEROCOPY": rng.choice(["", "0", "1"]),
+           # round 5: a small single-memcpy budget sends heap-buffer handles from ~1000 envs on through the host copy pool (transport 3:
+           # stand-ins delivered chunk by chunk while the kernel runs), not only the 16 401- and 32 768-env draws that exceed the default MiB
+           "DRONE_HOST_BOUNCE_MAX_BYTES": rng.choice(["", "", "60000"])}
     return {"task": task, "n": n, "seed": int(rng.integers(0, 1 << 62)), "device": bool(rng.integers(0, 2)), "over": over, "env": env,
             "graph_safe": bool(rng.random() < 0.25), "ops": int(rng.integers(3, 7) if big else rng.integers(4, 14)), "max_k": 3 if big else 9,
             "heap_buffers": bool(rng.random() < 0.3)}  # host handles: plain numpy arrays (pages shared with the heap: never pinned) instead of page-owning ones

@@ -199,7 +199,6 @@ def drive_and_compare(oracle, hip, task, n, paths, seed, steps, env_offset=0, **
     import torch
 
     h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(task, env_offset=env_offset, **over), device="cuda:0")
-    text, var = h.variant
     align = int(over.get("agents_per_env", 8)) if task == 2 else 1
     blocks = sampled_blocks(n, align=align)
     orc = []
@@ -208,6 +207,7 @@ def drive_and_compare(oracle, hip, task, n, paths, seed, steps, env_offset=0, **
         o.reset(seed)
         orc.append(o)
     h.reset(seed)
+    text, var = h.variant  # behind the first reset: an HBM-bound handle has measured its sweep order by now (round 5)
 
     def compare(what, obs, rew, term, trunc):
         for (start, count), o in zip(blocks, orc):

@@ -8,7 +8,7 @@ and CLOSED in turn: the allocators hand the next variant the same blocks and
 the comparison is at equal placement. `--fresh` keeps all variants alive
 instead (different placements; shows the spread).
 
-  python tools/ab_step.py [--envs N] [--rounds 8] [--steps 200] "name=-Dflags;ENV=val,ENV2=val" ...
+  python tools/ab_step.py [--envs N] [--rounds 8] [--steps 200] "name=-Dflags;ENV=val,ENV2=val" "old=@tools/ab_libs/lib.so" ...
 """
 import argparse
 import gc
@@ -134,6 +134,7 @@ def main():
         return v.timer_stop() * 1e3 / 10
 
     times = {k: [] for k in specs}
+    said = {k: [] for k in specs}  # drone_vec_variant() of every handle timed (an HBM-bound handle says which sweep order it measured and picked)
     live = {k: make(k) for k in specs} if a.fresh else None
     for rnd in range(a.rounds):
         for name in specs:
@@ -141,6 +142,7 @@ def main():
                 times[name].append(timeit(*live[name]))
             else:
                 v, ring = make(name)
+                said[name].append(v.variant[0].split("> ", 1)[-1])
                 times[name].append(timeit(v, ring))
                 torch.cuda.synchronize()
                 v.close()
@@ -153,7 +155,8 @@ def main():
         med = statistics.median(ts)
         base = base or med
         print(json.dumps({"variant": name, "spec": specs[name][2], "median_us": round(med, 2), "min_us": round(min(ts), 2),
-                          "max_us": round(max(ts), 2), "vs_first": round(med / base, 4), "all": [round(t, 1) for t in ts]}))
+                          "max_us": round(max(ts), 2), "vs_first": round(med / base, 4), "all": [round(t, 1) for t in ts],
+                          **({"handles": said[name]} if any("autotuned" in x for x in said[name]) else {})}))
 
 
 if __name__ == "__main__":
