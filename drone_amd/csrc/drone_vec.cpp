@@ -819,9 +819,9 @@ void write_variant(DroneVec* v, const char* tuned) {
 // plain sweep with non-temporal state loads (8) — all instantiations the parity suite covers (tests/soak_parity.py,
 // test_robustness_gpu.py: the order only permutes which workgroup takes which chunk and which loads carry a hint, never a
 // result). Timed on THIS handle's own planes and buffers — memory placement alone moves these kernels by several per cent,
-// so a scratch copy would measure another kernel — right behind a reset, in interleaved rounds of eight launches per
-// candidate with the step counter advancing (the reversed sweep keys on its parity); the caller's reset launch that follows
-// rewrites every plane, counter and output the trial steps touched. Costs ~75 launches once per handle (13 ms at 2^22 envs).
+// so a scratch copy would measure another kernel — right behind a reset, in bursts per candidate (below) with the step counter
+// advancing (the reversed sweep keys on its parity); the caller's reset launch that follows rewrites every plane, counter and
+// output the trial steps touched. Costs ~145 launches once per handle (26 ms at 2^22 envs).
 // The whole-line widening of rare plane updates stays with the table: no episode ends this soon after a reset, so the trial
 // cannot see what it is for.
 void autotune_sweep(DroneVec* v) {
@@ -843,16 +843,21 @@ void autotune_sweep(DroneVec* v) {
     }
     bool ok = launch_reset(v->dv, v->cfg.task, v->stream) == hipSuccess;
     uint32_t g = 0;
-    const int rounds = 3, per_round = 8;
-    for (int r = -1; r < rounds && ok; r++) {  // round -1: untimed, brings the clocks and the caches to where a run keeps them
+    // Each candidate runs in BURSTS of its own — eight untimed launches, then sixteen timed — twice over, the candidates taking
+    // turns: what distinguishes them is how they treat the Infinity Cache from one step to the next, and that settles only after a
+    // few launches of the same kind (a first version interleaved bursts of eight without the untimed lead-in and, at 2^21 envs,
+    // picked the plain sweep at 80 us that then ran at 96 in steady state, where the non-temporal one runs at 88).
+    const int rounds = 2, lead_in = 8, per_round = 16;
+    for (int r = 0; r < rounds && ok; r++) {
         for (int c = 0; c < nc && ok; c++) {
             v->dv.order = cand[c];
+            for (int k = 0; k < lead_in && ok; k++, g++) ok = launch_step(v->dv, v->cfg.task, g, g & 1u, v->stream) == hipSuccess;
             ok = ok && hipEventRecord(e0, v->stream) == hipSuccess;
             for (int k = 0; k < per_round && ok; k++, g++) ok = launch_step(v->dv, v->cfg.task, g, g & 1u, v->stream) == hipSuccess;
             ok = ok && hipEventRecord(e1, v->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
             float ms = 0.f;
             ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-            if (r >= 0) total[c] += ms;
+            total[c] += ms;
         }
     }
     (void)hipEventDestroy(e0);

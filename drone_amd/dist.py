@@ -238,7 +238,18 @@ class PeerStoreGather:
                 self.rew = torch.zeros(self.total, dtype=torch.float32, device=dev)
                 self.term = torch.zeros(self.total, dtype=torch.uint8, device=dev)
                 self.trunc = torch.zeros(self.total, dtype=torch.uint8, device=dev)
-                # a fresh name, created exclusively (never an existing file or a symlink someone planted under a guessable name), private to this user
+                # A job that is SIGKILLed between creating the page and unlinking it (below: once every rank has mapped it) leaves 4 KiB
+                # behind under a name that carries its pid: sweep what dead processes of this user left, then make a fresh name,
+                # created exclusively (never an existing file or a symlink someone planted under a guessable name), private to this user
+                for stale in os.listdir("/dev/shm"):
+                    if stale.startswith("drone_peer_flags_"):
+                        try:
+                            os.kill(int(stale.split("_")[3]), 0)
+                        except ProcessLookupError:
+                            with contextlib.suppress(OSError):
+                                os.unlink(os.path.join("/dev/shm", stale))
+                        except (ValueError, IndexError, PermissionError):
+                            pass
                 name = f"/dev/shm/drone_peer_flags_{os.getpid()}_{secrets.token_hex(8)}"
                 fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
                 self._flagfile = name

@@ -234,6 +234,7 @@ def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, wor
     """drone_amd.dist.PeerStoreGather: the same exchange behind the helper torch consumers (and bench.py) use — the token and
     the flag page's name cross torch.distributed (gloo here) once, in its constructor."""
     steps, seed = 40, 29
+    shm_before = set(os.listdir("/dev/shm"))
     script = tmp_path / "worker_dist.py"
     script.write_text(_WORKER_DIST.format(root=ROOT))
     store, out = str(tmp_path / "store"), str(tmp_path / "out.npz")
@@ -261,7 +262,8 @@ def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, wor
         for buf in (o.observations, o.rewards, o.terminals, o.truncations):
             crc = zlib.crc32(buf.tobytes(), crc)
     assert int(np.load(out)["crc"]) == crc
-    assert not [f for f in os.listdir("/dev/shm") if f.startswith("drone_peer_flags_")], "the flag page's name must be gone once every rank has mapped it"
+    left = [f for f in set(os.listdir("/dev/shm")) - shm_before if f.startswith("drone_peer_flags_")]
+    assert not left, f"the flag page's name must be gone once every rank has mapped it: {left}"
 
 
 def test_paths_the_handshake_cannot_cover_are_refused(hip):
