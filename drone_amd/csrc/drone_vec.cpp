@@ -146,9 +146,10 @@ struct DroneVec {
     void* pinned_blocks[64];
     int n_pinned_blocks;
     char variant[448];   // drone_vec_variant
-    // round 5: the sweep order / load hints of an HBM-bound handle are MEASURED on the box it runs on, once, at the first reset
-    // (autotune_sweep); the footprint table of drone_vec_init only nominates the candidates
-    bool autotune_pending;
+    // round 5: the sweep order / load hints of an HBM-bound handle are MEASURED on the box it runs on, under the workload it
+    // runs, during its first few hundred real steps (struct SweepTune); the footprint table of drone_vec_init only nominates
+    // the candidates and stands until the measurement is complete
+    struct SweepTune* tune;
     size_t touched_mib;  // MiB one step touches (the footprint the table is indexed by)
     // sticky status: the first failure of any call on this handle (drone_vec_status)
     int status;
@@ -662,6 +663,19 @@ struct Gather {
     float* own_obs = nullptr; float* own_rew = nullptr; unsigned char* own_term = nullptr; unsigned char* own_trunc = nullptr;  // the handle's output bindings before the exchange took them over
 };
 
+// (defined at global scope like Gather: DroneVec names it)
+struct SweepTune {
+    static constexpr int kStart = 160, kBurst = 16, kLead = 4, kRounds = 2, kPairs = 48;
+    uint32_t cand[4];
+    int nc = 0;
+    uint32_t table = 0;
+    long seen = 0;            // step launches of this handle so far
+    double sum_ms[4] = {0, 0, 0, 0};
+    int samples[4] = {0, 0, 0, 0};
+    struct Pair { hipEvent_t e0 = nullptr, e1 = nullptr; int cand = -1; } pairs[kPairs];
+    int in_flight = 0;
+};
+
 namespace {
 
 void gather_destroy(DroneVec* v) {
@@ -807,75 +821,103 @@ bool peer_before_launch(DroneVec* v, LaunchSig* sig) {
     return peer_wait_ge(v, g, g->world, 1, -1, g->seq);
 }
 
-// drone_vec_variant's text; `tuned`: " autotuned=1 tried=o0:181.2,o6:177.0,o8:175.3" once the first reset has measured the candidates
+// drone_vec_variant's text; `tuned`: " autotuned=1 table=8 tried=o8:170.1,o0:178.8,o6:170.3" once the handle has measured the candidates (SweepTune below)
 void write_variant(DroneVec* v, const char* tuned) {
     snprintf(v->variant, sizeof(v->variant), "drone_step_kernel<task=%d,compact=%d,mem=%u,dt=%d> order=%u line_complete=%u packed_rk4=%u bytes=%d%s",
              v->cfg.task, v->dv.done_ids ? 1 : 0, (v->dv.order >> 2) & 3u, v->dv.derived_target ? 1 : 0, v->dv.order, v->dv.line_complete,
              v->dv.packed_rk4, drone_vec_bytes_per_env_step(v), tuned ? tuned : "");
 }
 
-// Pick the per-step kernel's sweep order / load hints by MEASUREMENT (round 5). Candidates: the footprint table's entry and
-// its neighbours — a plain round-robin sweep (0), the sweep that turns around on odd steps with streamed action rows (6), a
-// plain sweep with non-temporal state loads (8) — all instantiations the parity suite covers (tests/soak_parity.py,
-// test_robustness_gpu.py: the order only permutes which workgroup takes which chunk and which loads carry a hint, never a
-// result). Timed on THIS handle's own planes and buffers — memory placement alone moves these kernels by several per cent,
-// so a scratch copy would measure another kernel — right behind a reset, in bursts per candidate (below) with the step counter
-// advancing (the reversed sweep keys on its parity); the caller's reset launch that follows rewrites every plane, counter and
-// output the trial steps touched. Costs ~145 launches once per handle (26 ms at 2^22 envs).
-// The whole-line widening of rare plane updates stays with the table: no episode ends this soon after a reset, so the trial
-// cannot see what it is for.
-void autotune_sweep(DroneVec* v) {
-    v->autotune_pending = false;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(v->stream, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (cap != hipStreamCaptureStatusNone || v->dv.ctr || (v->gather && v->gather->peer)) return;  // nothing may be replayed, advanced on the device or stored into a peer's batch by a trial
-    const uint32_t table = v->dv.order;
-    uint32_t cand[4] = {table, 0u, 6u, 8u};
-    int nc = 1;
-    for (int k = 1; k < 4; k++)
-        if (cand[k] != table) cand[nc++] = cand[k];
-    float total[4] = {0.f, 0.f, 0.f, 0.f};
-    hipEvent_t e0 = nullptr, e1 = nullptr;  // its own pair: a caller's drone_vec_timer_start may be pending on the handle's
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-        (void)hipGetLastError();
-        if (e0) (void)hipEventDestroy(e0);
-        return;
+// Pick the per-step kernel's sweep order / load hints by MEASUREMENT (round 5) — ONLINE, on the handle's real
+// steps. Candidates: the footprint table's entry and its neighbours — a plain round-robin sweep (0), the sweep that turns
+// around on odd steps with streamed action rows (6), a plain sweep with non-temporal state loads (8) — all instantiations the
+// parity suite and the soak cover: the order only permutes which workgroup takes which chunk and which loads carry a hint,
+// never a result, so real steps may run under any of them. From the handle's 161st step launch on, the candidates take turns
+// in bursts of sixteen steps, twice each; every launch of a burst but its first four (the cache is still in the previous
+// candidate's state) sits between two HIP events on the stream, read back lazily (hipEventQuery) when later calls find them
+// complete — nothing waits, nothing extra is launched, no state or output is touched. When every candidate has its samples
+// the fastest becomes the handle's order and drone_vec_variant() says what was measured
+// (" autotuned=1 table=8 tried=o8:170.1,o0:178.8,o6:170.3").
+// Why online: a first version timed trial steps right behind the first reset (profiles/r05_ab/autotune_offline_*.txt). No
+// episode ends that soon after a reset — and the ranking depends on them: at 2^21 hover envs the plain sweep ran 80.8 us in
+// that trial and 94.5 in steady state under the random policy (one episode end per 146 env-steps; the scattered log-plane and
+// target updates cost it its cache residency), where the non-temporal sweep it "beat" runs 86.2 either way; at 2^23 the trial
+// picked order 8, 4 % behind order 6 in steady state. The table, tuned in steady state, was right in all eight cases on two
+// boxes; the offline trial in five. What a handle should measure is the workload it actually runs.
+void tune_free(DroneVec* v) {
+    if (!v->tune) return;
+    for (auto& p : v->tune->pairs) {
+        if (p.e0) (void)hipEventDestroy(p.e0);
+        if (p.e1) (void)hipEventDestroy(p.e1);
     }
-    bool ok = launch_reset(v->dv, v->cfg.task, v->stream) == hipSuccess;
-    uint32_t g = 0;
-    // Each candidate runs in BURSTS of its own — eight untimed launches, then sixteen timed — twice over, the candidates taking
-    // turns: what distinguishes them is how they treat the Infinity Cache from one step to the next, and that settles only after a
-    // few launches of the same kind (a first version interleaved bursts of eight without the untimed lead-in and, at 2^21 envs,
-    // picked the plain sweep at 80 us that then ran at 96 in steady state, where the non-temporal one runs at 88).
-    const int rounds = 2, lead_in = 8, per_round = 16;
-    for (int r = 0; r < rounds && ok; r++) {
-        for (int c = 0; c < nc && ok; c++) {
-            v->dv.order = cand[c];
-            for (int k = 0; k < lead_in && ok; k++, g++) ok = launch_step(v->dv, v->cfg.task, g, g & 1u, v->stream) == hipSuccess;
-            ok = ok && hipEventRecord(e0, v->stream) == hipSuccess;
-            for (int k = 0; k < per_round && ok; k++, g++) ok = launch_step(v->dv, v->cfg.task, g, g & 1u, v->stream) == hipSuccess;
-            ok = ok && hipEventRecord(e1, v->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
-            float ms = 0.f;
-            ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-            total[c] += ms;
+    delete v->tune;
+    v->tune = nullptr;
+}
+
+void tune_harvest(SweepTune* t) {
+    for (auto& p : t->pairs) {
+        if (p.cand < 0) continue;
+        const hipError_t q = hipEventQuery(p.e1);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
+        float ms = 0.f;
+        if (q == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            t->sum_ms[p.cand] += ms;
+            t->samples[p.cand] += 1;
+        } else {
+            (void)hipGetLastError();
         }
+        p.cand = -1;
+        t->in_flight -= 1;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (!ok) {  // leave the table's choice; the reset that follows reports whatever is wrong with the stream
-        (void)hipGetLastError();
-        v->dv.order = table;
-        return;
+}
+
+// called around every per-step launch of a handle that is still measuring: before it (returns the event pair to close behind the
+// launch, or null) — may change v->dv.order for this launch
+SweepTune::Pair* tune_before_step(DroneVec* v) {
+    SweepTune* t = v->tune;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(v->stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone || v->dv.ctr || (v->gather && v->gather->peer)) {
+        (void)hipGetLastError();  // a capture, graph-safe counters or a peer-store exchange: the table's choice stands for good
+        v->dv.order = t->table;
+        tune_free(v);
+        return nullptr;
     }
-    int best = 0;
-    for (int c = 1; c < nc; c++)
-        if (total[c] < total[best]) best = c;
-    v->dv.order = cand[best];
-    char tuned[200];
-    int at = snprintf(tuned, sizeof(tuned), " autotuned=1 table=%u tried=", table);
-    for (int c = 0; c < nc && at < (int)sizeof(tuned) - 16; c++)
-        at += snprintf(tuned + at, sizeof(tuned) - at, "%so%u:%.1f", c ? "," : "", cand[c], total[c] * 1e3f / (rounds * per_round));
-    write_variant(v, tuned);
+    tune_harvest(t);
+    const long k = t->seen++ - SweepTune::kStart;
+    if (k < 0) return nullptr;
+    const long burst = k / SweepTune::kBurst;
+    if (burst >= (long)t->nc * SweepTune::kRounds) {  // exploration is over: decide once every pair has been read
+        v->dv.order = t->table;
+        if (t->in_flight > 0) return nullptr;
+        int best = -1;
+        for (int c = 0; c < t->nc; c++)
+            if (t->samples[c] >= SweepTune::kBurst / 2 && (best < 0 || t->sum_ms[c] / t->samples[c] < t->sum_ms[best] / t->samples[best])) best = c;
+        char tuned[200];
+        int at = 0;
+        if (best >= 0 && t->samples[0] >= SweepTune::kBurst / 2) {  // (without enough samples of the table's own entry there is nothing to compare with)
+            v->dv.order = t->cand[best];
+            at = snprintf(tuned, sizeof(tuned), " autotuned=1 table=%u tried=", t->table);
+            for (int c = 0; c < t->nc && at < (int)sizeof(tuned) - 16; c++)
+                at += snprintf(tuned + at, sizeof(tuned) - at, "%so%u:%.1f", c ? "," : "", t->cand[c], t->samples[c] ? t->sum_ms[c] * 1e3 / t->samples[c] : 0.0);
+        } else {
+            snprintf(tuned, sizeof(tuned), " autotuned=0 table=%u", t->table);
+        }
+        tune_free(v);
+        write_variant(v, tuned);
+        return nullptr;
+    }
+    const int c = (int)(burst % t->nc);
+    v->dv.order = t->cand[c];
+    if (k % SweepTune::kBurst < SweepTune::kLead) return nullptr;
+    for (auto& p : t->pairs) {
+        if (p.cand >= 0) continue;
+        if (!p.e0 && (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess)) { (void)hipGetLastError(); return nullptr; }
+        if (hipEventRecord(p.e0, v->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        p.cand = c;
+        t->in_flight += 1;
+        return &p;
+    }
+    return nullptr;  // every pair is still in flight (a caller far ahead of the device): this launch goes unmeasured
 }
 
 }  // namespace
@@ -1202,12 +1244,21 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         v->dv.order = (o && *o) ? (uint32_t)atoi(o) : order;
         // Beyond 400 MiB the table's entry is only the FIRST candidate: the adopted differences between the orders there
         // (-1.8 ... -3 % at 2^22 envs) are smaller than the spread of one binary across boxes of the pool (+-5 %), and the
-        // driver's box disagreed with the table at 2^22 against 2^23. The first reset times the candidates
-        // on this box, on this handle's own buffers (autotune_sweep). Not for a forced order, host buffers (PCIe-bound at
-        // these sizes) or DRONE_AUTOTUNE=0.
+        // driver's box disagreed with the table at 2^22 against 2^23. The handle's own steps 161 ... 256 time
+        // the candidates on this box, on its own buffers, under its own workload (SweepTune). Not for a forced order, host
+        // buffers (PCIe-bound at these sizes) or DRONE_AUTOTUNE=0.
         const char* at = getenv("DRONE_AUTOTUNE");
         v->touched_mib = mib;
-        v->autotune_pending = mib > 400 && !(o && *o) && !v->host_buffers && !(at && *at && atoi(at) == 0);
+        if (mib > 400 && !(o && *o) && !v->host_buffers && !(at && *at && atoi(at) == 0)) {
+            v->tune = new (std::nothrow) SweepTune();
+            if (v->tune) {
+                v->tune->table = order;
+                const uint32_t all[3] = {0u, 6u, 8u};
+                v->tune->cand[v->tune->nc++] = order;
+                for (uint32_t c : all)
+                    if (c != order) v->tune->cand[v->tune->nc++] = c;
+            }
+        }
     }
     {   // Packed-f32 RK4 in the register-resident kernels (fused rollout, step_many): wins only while a SIMD holds ONE
         // wave (<= 65 536 envs on the 1024 SIMDs: rollout -8.8 %, step_many -3.9 %; waypoint / race -3...4 %), where the
@@ -1235,9 +1286,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->list_valid = false;
     v->many_k = 0;
     LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
-    if (!upload_params(v)) return;
-    if (v->autotune_pending) autotune_sweep(v);  // first reset of an HBM-bound handle: measure the sweep order on this box (the launch below restores everything)
-    if (!push_counters(v) || !peer_before_launch(v, &sig)) return;
+    if (!upload_params(v) || !push_counters(v) || !peer_before_launch(v, &sig)) return;
     HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream, &sig), return);
     if (v->host_buffers) device_to_host_outputs(v);
 }
@@ -1252,7 +1301,13 @@ bool step_send_impl(DroneVec* v) {
         sig.wg_done = v->d_wg_done;
         sig.wg_done_value = ++v->wg_seq;
     }
+    SweepTune::Pair* timing = v->tune ? tune_before_step(v) : nullptr;  // an HBM-bound handle still measuring its sweep order (may set dv.order for this launch)
     HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream, &sig), return false);
+    if (timing && hipEventRecord(timing->e1, v->stream) != hipSuccess) {  // (v->tune is still there: a pair is only handed out while measuring)
+        (void)hipGetLastError();
+        timing->cand = -1;
+        v->tune->in_flight -= 1;
+    }
     v->gstep += 1;
     v->step_launches += 1;
     v->list_valid = true;
@@ -1446,6 +1501,7 @@ void drone_vec_close(DroneVec* v) {
     (void)hipSetDevice(v->device);
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     if (v->copy_started) (void)finish_threaded_copy(v);  // closed between step_send and step_recv: the pool must let go of this handle first
+    tune_free(v);
     gather_destroy(v);
     if (v->h_wg_done) (void)hipHostFree(v->h_wg_done);
     for (int i = 0; i < 5; i++)

@@ -7,6 +7,22 @@ from drone_amd import abi
 STATE_FIELDS = abi.state_row_dtype().names
 
 
+def usable_cores():
+    """Threads worth giving the oracle on THIS box: the affinity mask and the cgroup quota, not the machine's core count
+    (os.cpu_count() reports the host's; OpenMP teams larger than the quota spend their time in barriers)."""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def to_np(x):
     return x.cpu().numpy() if type(x).__module__.startswith("torch") else np.asarray(x)
 

@@ -267,19 +267,11 @@ def test_every_handle_bench_times_matches_the_oracle(oracle, hip, task_name, n, 
     over = dict(horizon=25) if n > (1 << 20) else {}
     var, ended = drive_and_compare(oracle, hip, TASK_IDS[task_name], n, paths, seed=41, steps=steps, **over)
     want = EXPECTED_VARIANT.get((task_name, n))
-    if var.get("autotuned"):
-        # round 5: beyond 400 MiB per step the sweep order / load hints are MEASURED at the first reset on
-        # the box at hand; the footprint table only nominates the candidates. The pick must be one of the instantiations the
-        # parity suite covers (tests/soak_parity.py draws exactly these orders), and this very run has just compared it with
-        # the oracle; everything that is not a speed choice stays what the table says.
-        assert var["order"] in (0, 6, 8) and var["mem"] == (var["order"] >> 2) & 3, var
-        if want:
-            assert var["table"] == want["order"], f"the table's candidate for {task_name} x {n} changed: {var}"
-            fixed = lambda d: {k: x for k, x in d.items() if k not in ("order", "mem", "autotuned", "table")}  # noqa: E731
-            assert fixed(var) == fixed(want), (var, want)
-    elif want:
-        assert n * want["bytes"] <= 400 << 20, f"a handle of {n} envs ({task_name}) was not autotuned: {var}"
-        assert var == want, f"a {task_name} handle of {n} envs now picks {var}; bench.py's figures and DESIGN.md assume {want}"
+    # round 5: beyond 400 MiB per step a handle MEASURES its sweep order / load hints on its own steps 161-256
+    # (tests/test_robustness_gpu.py follows one through that); these runs are shorter, so what ran here is the footprint table's
+    # entry — or, under it, candidates of the tested set {0, 6, 8} for a few steps — and the variant string is still the table's
+    if want:
+        assert {k: x for k, x in var.items() if k not in ("autotuned", "table")} == want, f"a {task_name} handle of {n} envs now picks {var}; bench.py's figures and DESIGN.md assume {want}"
     assert ended > 0, "no episode ended in the sampled blocks: the episode-end path went unchecked"
 
 

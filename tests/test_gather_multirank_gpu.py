@@ -11,6 +11,8 @@ import zlib
 import numpy as np
 import pytest
 
+from helpers import usable_cores
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE_MP = os.path.join(ROOT, "host", "drone_host_mp")
@@ -66,7 +68,7 @@ def test_world8_at_the_real_shape_c_host_mp(stub, oracle, envs, rollout, root):
     assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
     got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert got["gpus"] == 8 and got["envs"] == envs and got["root"] == root
-    crc, own = oracle_crcs(oracle, envs, 0, seed, steps, rollout, ranks, threads=os.cpu_count() or 4)
+    crc, own = oracle_crcs(oracle, envs, 0, seed, steps, rollout, ranks, threads=usable_cores())
     assert got["rank_crc32"] == own, [r for r in range(ranks) if got["rank_crc32"][r] != own[r]]
     assert got["crc32"] == crc, f"8 ranks x {envs // 8} envs: gathered crc {got['crc32']:#x} != oracle {crc:#x}"
 
@@ -168,7 +170,7 @@ def test_in_place_device_gather_across_ranks(stub, oracle, tmp_path, world, tota
     for p in procs:
         so, se = p.communicate(timeout=600)
         assert p.returncode == 0, se[-3000:]
-    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=4 if total < 200000 else (os.cpu_count() or 4))
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=4 if total < 200000 else usable_cores())
     o.reset(seed)
     for _ in range(steps):
         o.fill_random_actions()

@@ -13,6 +13,8 @@ import zlib
 import numpy as np
 import pytest
 
+from helpers import usable_cores
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -124,7 +126,7 @@ def test_peer_stores_land_every_ranks_rows_in_the_roots_batch(oracle, hip, tmp_p
     over = dict(horizon=20)
     if task == 2:
         over.update(agents_per_env=8, collision_radius=0.5)
-    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, **over), threads=(os.cpu_count() or 4) if big else 4)
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, **over), threads=usable_cores() if big else 4)
     o.reset(seed)
     crc = 0
     for buf in (o.observations, o.rewards, o.terminals, o.truncations):
@@ -176,7 +178,7 @@ def test_plain_c_host_peer_store_exchange(oracle, hip, ranks, envs, task, rollou
 
     got = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert got["root"] == root and "peer-store" in got["mode"] and got["gpus"] == ranks
-    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=(os.cpu_count() or 4) if big else 4)
+    o = oracle.OracleVec(envs, seed=seed, cfg=oracle.default_config(task), threads=usable_cores() if big else 4)
     o.reset(seed)
     crc = zlib.crc32(o.observations.tobytes())
     launches = steps if not rollout else (steps + rollout - 1) // rollout
@@ -251,7 +253,7 @@ def test_peer_store_gather_helper_for_torch_consumers(oracle, hip, tmp_path, wor
             if p.poll() is None:
                 p.kill()
     assert all(rc == 0 for rc, _ in errs), "\n".join(f"--- rc {rc}\n{se[-1500:]}" for rc, se in errs)
-    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=os.cpu_count() or 4)
+    o = oracle.OracleVec(total, seed=seed, cfg=oracle.default_config(task, horizon=20), threads=usable_cores())
     o.reset(seed)
     crc = 0
     for buf in (o.observations, o.rewards, o.terminals, o.truncations):

@@ -228,55 +228,62 @@ def test_sweep_orders_are_bijective(oracle, hip, monkeypatch, order, n):
     assert_state_equal(o.get_state(), h.get_state(), f"order {order} state after rollout")
 
 
-def test_autotuned_sweep_leaves_no_trace_but_its_name(hip, monkeypatch):
-    """Round 5: a handle whose step touches more than 400 MiB measures its sweep order at the first reset —
-    on its own planes and buffers, with trial steps the reset that follows must erase completely. The handle says what it tried
-    (drone_vec_variant); DRONE_AUTOTUNE=0 keeps the footprint table's pick and says nothing; a forced order is not second-guessed;
-    both handles then walk the same trajectory, outputs and done lists included, and a SECOND reset does not tune again."""
+def test_sweep_order_measured_on_the_handles_own_steps(hip, monkeypatch):
+    """Round 5: a handle whose step touches more than 400 MiB measures its sweep order ONLINE — from its 161st
+    step launch on the candidates 0 / 6 / 8 take turns in bursts of sixteen real steps, timed by HIP events read back lazily;
+    nothing extra is launched. Until the measurement is complete the footprint table's pick stands and the handle says nothing;
+    afterwards it names what it tried and runs the fastest. DRONE_AUTOTUNE=0 keeps the table for good; a forced order is not
+    second-guessed. A sweep order only permutes which workgroup takes which chunk: all three handles walk the same trajectory,
+    outputs and done lists included — also THROUGH the steps in which the order changes every sixteen launches."""
     import zlib
 
     from helpers import to_np
 
     n, seed = (1 << 21) + 300, 11  # 2.1 M hover envs (derived-target layout): 524 MiB per step, ragged last workgroup
 
-    def run(h):
-        h.reset(seed)
-        first_obs = zlib.crc32(to_np(h.observations).tobytes())
-        assert not to_np(h.terminals).any() and not to_np(h.rewards).any() and h.gstep == 0 and len(h.done_list()) == 0
-        for _ in range(30):
+    def run(h, steps, digests_at):
+        out = {}
+        for t in range(steps):
             h.fill_random_actions()
             h.step()
-        st = h.get_state()
-        out = [zlib.crc32(np.ascontiguousarray(st[f]).tobytes()) for f in st.dtype.names]
-        out += [zlib.crc32(to_np(x).tobytes()) for x in (h.observations, h.rewards, h.terminals, h.truncations)]
-        return first_obs, out, np.sort(h.done_list())
+            if t + 1 in digests_at:
+                st = h.get_state()
+                d = [zlib.crc32(np.ascontiguousarray(st[f]).tobytes()) for f in st.dtype.names]
+                d += [zlib.crc32(to_np(x).tobytes()) for x in (h.observations, h.rewards, h.terminals, h.truncations)]
+                out[t + 1] = (d, np.sort(h.done_list()))
+        return out
 
+    at = (150, 170, 200, 230, 320)  # before the measurement, inside three different bursts, after it
     h = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
-    before, _ = h.variant
-    assert "autotuned" not in before  # nothing measured yet: the table's candidate
-    a = run(h)
+    h.reset(seed)
+    assert "autotuned" not in h.variant[0]
+    a = run(h, 320, at)
+    h.sync()
+    h.fill_random_actions(); h.step()  # (the decision is taken by a step call once every event has been read)
     text, var = h.variant
     assert var["autotuned"] == 1 and var["order"] in (0, 6, 8) and var["table"] in (0, 6, 8) and var["mem"] == (var["order"] >> 2) & 3, text
     tried = dict(kv.split(":") for kv in text.split("tried=")[1].split()[0].split(","))
     assert set(tried) == {"o0", "o6", "o8"} and all(20.0 < float(us) < 2000.0 for us in tried.values()), text
     assert float(tried[f"o{var['order']}"]) == min(float(us) for us in tried.values())
-    again = run(h)  # a second reset: same trajectory, no second measurement
-    assert h.variant[0] == text and again[0] == a[0] and again[1] == a[1] and np.array_equal(again[2], a[2])
+    h.reset(seed)  # a reset later on changes nothing: measured once per handle
+    assert h.variant[0] == text
     h.close()
     monkeypatch.setenv("DRONE_AUTOTUNE", "0")
     h0 = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
-    b = run(h0)
+    h0.reset(seed)
+    b = run(h0, 320, at)
     assert "autotuned" not in h0.variant[0] and h0.variant[1]["order"] == var["table"]
     h0.close()
     monkeypatch.delenv("DRONE_AUTOTUNE")
     monkeypatch.setenv("DRONE_SWEEP_ORDER", "2")
     h2 = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
-    c = run(h2)
+    h2.reset(seed)
+    c = run(h2, 320, at)
     assert "autotuned" not in h2.variant[0] and h2.variant[1]["order"] == 2
     h2.close()
     for other, name in ((b, "DRONE_AUTOTUNE=0"), (c, "forced order 2")):
-        assert other[0] == a[0], f"{name}: observations right after the reset differ: a trial step survived it"
-        assert other[1] == a[1] and np.array_equal(other[2], a[2]), f"{name}: trajectories differ from the autotuned handle's"
+        for t in at:
+            assert other[t][0] == a[t][0] and np.array_equal(other[t][1], a[t][1]), f"{name}: after {t} steps the trajectory differs from the measuring handle's"
 
 
 @pytest.mark.parametrize("task", [0, 1, 3])

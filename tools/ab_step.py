@@ -142,8 +142,8 @@ def main():
                 times[name].append(timeit(*live[name]))
             else:
                 v, ring = make(name)
-                said[name].append(v.variant[0].split("> ", 1)[-1])
                 times[name].append(timeit(v, ring))
+                said[name].append(v.variant[0].split("> ", 1)[-1])  # behind the timed steps: a handle that measures its sweep order on its first ~260 steps has said so by now
                 torch.cuda.synchronize()
                 v.close()
                 for r in v._raw:
