@@ -117,7 +117,7 @@ def main():
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
     # rollout_valu.json: VALU instructions per wave-step from the SQ pass + ISA mix of the same sources
     try:
-        c = json.load(open(os.path.join(SRC, "sq_rollout_hover", "pmc_avg.json")))
+        c = json.load(open(os.path.join(SRC, "sq_rollout_hover_a" if os.path.isdir(os.path.join(SRC, "sq_rollout_hover_a")) else "sq_rollout_hover", "pmc_avg.json")))
         k = next(v for n, v in c.items() if "rollout" in n)
         per = k["SQ_INSTS_VALU"] / k["SQ_WAVES"] / 128.0
         note = (f"SQ_INSTS_VALU {k['SQ_INSTS_VALU']:.4g} / {k['SQ_WAVES']:.0f} waves / 128 steps (profiles/{ROUND}_rollout_hover/sq_counters.json, build {build.get('git_head', '?')[:12]}); "
