@@ -511,10 +511,16 @@ void leave_zero_copy(DroneVec* v) {
 // later unregistering) a range that shares a page with OTHER heap memory breaks the runtime's own on-the-fly pinning of
 // pageable copy destinations on that page: a later hipMemcpy / torch .cpu() into a neighbouring allocation dies with
 // "Memory access fault by GPU ... on address <heap address>" (tools/debug/pageable_copy_stress.py reproduces it with
-// plain HIP calls; ~1 in 12 runs of this repo's GPU test suite hit it before this rule). So a buffer is registered only
-// when its pages are provably its own: it starts on a page boundary and either spans whole pages or the caller vouches
-// for the tail of the last page (cfg.host_pages_exclusive). Memory the caller pinned itself (hipHostMalloc,
-// hipHostRegister) is used as it is. Everything else is left alone and goes through plain pageable copies.
+// plain HIP calls; ~1 in 12 runs of this repo's GPU test suite hit it before this rule). Round 5 found the rule of rounds
+// 3-4 — "starts on a page boundary and spans whole pages" — still too generous: such a block INSIDE the malloc heap (a
+// numpy array that happens to start on a page boundary, a posix_memalign block) owns its pages but not its mapping, and
+// when the heap around it is trimmed or reused while the GPU writes the registered pages the same fault appears ("Write
+// access to a read-only page": tools/debug/heap_interior_registration_stress.py, library-free; two of eight soak runs died
+// of it once heap-buffer handles took the zero-copy transports more often). A mapping of its own (mmap, POSIX shm) under
+// the same stress never faults. The library cannot tell the two apart, so alignment alone no longer suffices: a buffer is
+// registered only when the CALLER vouches for it (cfg.host_pages_exclusive: every buffer is a mapping of its own, page-
+// aligned, nothing else in its pages) or has pinned it itself (hipHostMalloc, hipHostRegister). Everything else is left
+// alone and goes through stand-ins or plain pageable copies.
 constexpr uintptr_t kPage = 4096;
 
 // Pinned by its owner (hipHostMalloc / hipHostRegister) over ALL of [p, p + bytes): the first and the last byte are both
@@ -541,8 +547,7 @@ bool pin_caller_buffer(DroneVec* v, int slot, void* p, size_t bytes) {
     v->registered_ptr[slot] = p;
     if (already_pinned(p, bytes)) return true;
     const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0;
-    const bool whole = (bytes % kPage) == 0;
-    if (!aligned || !(whole || v->cfg.host_pages_exclusive)) return false;
+    if (!aligned || !v->cfg.host_pages_exclusive) return false;
     const size_t span = (bytes + kPage - 1) / kPage * kPage;
     v->registered[slot] = (host_register(p, span, v, "caller buffer") == hipSuccess);
     if (!v->registered[slot]) (void)hipGetLastError();
@@ -1005,9 +1010,9 @@ int drone_vec_host_pin(DroneVec* v, void* p, size_t bytes, int pages_exclusive) 
     if (!in) return -1;
     if (!p || !bytes) { set_err("host_pin: NULL block or zero size"); return -1; }
     if (already_pinned(p, bytes)) return 0;  // the owner's registration: used as it is, never dropped by host_unpin
-    const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0, whole = (bytes % kPage) == 0;
-    if (!aligned || !(whole || pages_exclusive)) {
-        set_err("host_pin: the block must start on a 4 KiB boundary and span whole pages (or be vouched for: pages_exclusive), see DroneConfig.host_pages_exclusive");
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) % kPage) == 0;
+    if (!aligned || !pages_exclusive) {
+        set_err("host_pin: the block must start on a 4 KiB boundary and be vouched for (pages_exclusive = 1: a mapping of its own - mmap, shm - padded to whole pages; not a block of the malloc heap), see DroneConfig.host_pages_exclusive");
         return -1;
     }
     const int cap = (int)(sizeof(v->pinned_blocks) / sizeof(v->pinned_blocks[0]));
@@ -1945,7 +1950,7 @@ int drone_vec_gather_init_root(DroneVec* v, const unsigned char* id, int rank, i
             void* hosts[4] = {all_observations, all_rewards, all_terminals, all_truncations};
             const size_t bytes[4] = {g->total * od * sizeof(float), g->total * sizeof(float), g->total, g->total};
             for (int k = 0; k < 4; k++) {  // pinned only when the pages are the buffer's own (pin_caller_buffer's rule)
-                const bool own_pages = (reinterpret_cast<uintptr_t>(hosts[k]) % kPage) == 0 && ((bytes[k] % kPage) == 0 || v->cfg.host_pages_exclusive);
+                const bool own_pages = (reinterpret_cast<uintptr_t>(hosts[k]) % kPage) == 0 && v->cfg.host_pages_exclusive;
                 g->h_registered[k] = own_pages && !already_pinned(hosts[k], bytes[k]) &&
                                      host_register(hosts[k], (bytes[k] + kPage - 1) / kPage * kPage, v, "global gather buffer") == hipSuccess;
                 if (own_pages && !g->h_registered[k]) (void)hipGetLastError();

@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/mman.h>
 #include <string.h>
 #include <time.h>
 
@@ -26,10 +27,12 @@
 /* A zeroed buffer that owns its pages (page-aligned, padded to whole pages): what DroneConfig.host_pages_exclusive
  * vouches for, so that the library may pin it for the zero-copy transport. */
 static void* page_alloc(size_t bytes) {
-    void* p = NULL;
-    const size_t span = (bytes + 4095) / 4096 * 4096;
-    if (posix_memalign(&p, 4096, span ? span : 4096) != 0) return NULL;
-    memset(p, 0, span ? span : 4096);
+    /* a mapping of its own (round 5: a posix_memalign block owns its pages but lies inside the malloc heap, and registered heap
+     * pages fault when the heap around them is trimmed while the GPU writes them: tools/debug/heap_interior_registration_stress.py) */
+    const size_t span = bytes ? (bytes + 4095) / 4096 * 4096 : 4096;
+    void* p = mmap(NULL, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return NULL;
+    memset(p, 0, span);
     return p;
 }
 
@@ -154,7 +157,7 @@ int main(int argc, char** argv) {
         printf("{\"mode\": \"crc\", \"task\": %d, \"envs\": %d, \"steps\": %d, \"steps_per_call\": %d, \"crc32\": %u, \"episodes\": %.0f}\n", task, envs, steps, many > 0 ? many : 1, crc, lg.n);
         if (many > 0) { drone_vec_host_unpin(v, m_act); drone_vec_host_unpin(v, m_obs); drone_vec_host_unpin(v, m_rew); drone_vec_host_unpin(v, m_term); drone_vec_host_unpin(v, m_trunc); }
         drone_vec_close(v);
-        if (!heap) { free(obs); free(act); free(rew); free(term); free(trunc); }
+        /* (the buffers are mappings of their own or never-freed heap blocks: the process ends here) */
         return 0;
     }
 
@@ -199,7 +202,6 @@ int main(int argc, char** argv) {
     if (drone_vec_status(v)) { fprintf(stderr, "a call on the handle failed: %s\n", drone_vec_status_message(v)); return 1; }
     if (many > 0) { drone_vec_host_unpin(v, m_act); drone_vec_host_unpin(v, m_obs); drone_vec_host_unpin(v, m_rew); drone_vec_host_unpin(v, m_term); drone_vec_host_unpin(v, m_trunc); }
     drone_vec_close(v);
-    if (!heap) { free(obs); free(act); free(rew); free(term); free(trunc); }
-    free(m_act); free(m_obs); free(m_rew); free(m_term); free(m_trunc);
+    /* (the buffers are mappings of their own or never-freed heap blocks: the process ends here) */
     return 0;
 }

@@ -48,10 +48,12 @@
 /* A zeroed buffer that owns its pages (page-aligned, padded to whole pages): what DroneConfig.host_pages_exclusive
  * vouches for, so that the library may pin it for the zero-copy transport. */
 static void* page_alloc(size_t bytes) {
-    void* p = NULL;
-    const size_t span = (bytes + 4095) / 4096 * 4096;
-    if (posix_memalign(&p, 4096, span ? span : 4096) != 0) return NULL;
-    memset(p, 0, span ? span : 4096);
+    /* a mapping of its own (round 5: a posix_memalign block owns its pages but lies inside the malloc heap, and registered heap
+     * pages fault when the heap around them is trimmed while the GPU writes them: tools/debug/heap_interior_registration_stress.py) */
+    const size_t span = bytes ? (bytes + 4095) / 4096 * 4096 : 4096;
+    void* p = mmap(NULL, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return NULL;
+    memset(p, 0, span);
     return p;
 }
 
@@ -230,7 +232,7 @@ static int run_rank_peer(const Opts* o, int rank, Shared* sh, void* flag_page) {
     drone_vec_close(v);
     if (rank == root) {
         drone_device_free(cfg.device, g_obs); drone_device_free(cfg.device, g_rew); drone_device_free(cfg.device, g_term); drone_device_free(cfg.device, g_trunc);
-        free(h_obs); free(h_rew); free(h_term); free(h_trunc);
+        /* (h_*: mappings of their own, released with the process) */
     }
     return 0;
 }
@@ -257,10 +259,11 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     DroneConfig cfg;
     drone_config_default(&cfg, o->task);
     cfg.buffer_kind = DRONE_BUFFERS_HOST;
-    /* The four global buffers come from page_alloc (each owns its pages), so the gather may pin them whole; this rank's
-     * local output buffers are SLICES of them at arbitrary offsets and share pages with the neighbours' rows — with one
-     * rank the slice is the whole buffer, with several it is not, and the library then simply copies (mirror transport). */
-    cfg.host_pages_exclusive = world == 1 ? 1 : 0;
+    /* Every buffer here comes from page_alloc — a mapping of its own, never the malloc heap — which is what the flag vouches
+     * for (round 5: the library no longer registers on alignment alone). The gather pins the four global buffers whole; this
+     * rank's local output buffers are SLICES of them: one that does not start on a page boundary is never registered (the
+     * library copies), one that does lies inside our own mapping, and the gather drops the local pins anyway. */
+    cfg.host_pages_exclusive = 1;
     cfg.device = rank; /* one process per GPU */
     if (o->share) {
         const int ndev = drone_device_count();
@@ -342,7 +345,7 @@ static int run_rank(const Opts* o, int rank, Shared* sh) {
     }
     if (o->gather) drone_vec_gather_close(v);
     drone_vec_close(v);
-    free(all_obs); free(all_rew); free(all_term); free(all_trunc); free(act);
+    /* (the host buffers are mappings of their own, released with the process) */
     return 0;
 }
 

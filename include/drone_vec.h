@@ -39,7 +39,7 @@ extern "C" {
 #define DRONE_TASK_SWARM 2    /* agents_per_env drones per env, coupled by a nearest-neighbour term (SPEC.md §10) */
 #define DRONE_TASK_RACE 3     /* fly through a sequence of ring gates (SPEC.md §11) */
 
-#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory. Buffers that own their pages (see host_pages_exclusive) are pinned + mapped and the kernel accesses them over PCIe; others get pinned stand-ins (small shards) or go through H2D, kernel, D2H copies; step ends with a sync */
+#define DRONE_BUFFERS_HOST 0   /* caller buffers are host memory. Buffers the caller vouches for (host_pages_exclusive: mappings of their own) are pinned + mapped and the kernel accesses them over PCIe; others get pinned stand-ins (small and mid-size shards) or go through H2D, kernel, D2H copies; step ends with a sync */
 #define DRONE_BUFFERS_DEVICE 1 /* caller buffers are HBM on `device`: zero-copy, async on the stream */
 
 /* Env kwargs. Fill with drone_config_default() first, then override. */
@@ -63,14 +63,18 @@ typedef struct DroneConfig {
     float c_omega, c_action, crash_penalty, progress_scale, waypoint_bonus;
     float collision_radius, proximity_radius, c_proximity; /* task 2 */
     float gate_radius;                                      /* task 3 */
-    /* Host buffers only. 1: the caller guarantees that each of the five buffers starts on a 4 KiB page boundary and
-     * that nothing else lives in its pages up to the end of its last page (its own mmap / posix_memalign block, padded
-     * to whole pages). Such buffers are pinned and mapped for the zero-copy transport. 0 (default): a buffer is pinned
-     * only if it is page-aligned AND a whole number of pages long, or already pinned by the caller (hipHostMalloc /
-     * hipHostRegister); everything else is copied through pageable transfers and never registered. Why: on ROCm 7,
-     * hipHostRegister / hipHostUnregister of a range that SHARES a page with other heap memory breaks the runtime's
-     * own on-the-fly pinning of pageable copy destinations on that page ("Memory access fault by GPU ... on address
-     * <heap address>", tools/debug/pageable_copy_stress.py reproduces it without this library). */
+    /* Host buffers only. 1: the caller guarantees that each of the five buffers is a MAPPING OF ITS OWN — mmap, POSIX shm, a
+     * System V segment — that starts on a 4 KiB page boundary, with nothing else in its pages up to the end of its last page,
+     * and that stays mapped while the handle lives. Such buffers are pinned and mapped for the zero-copy transport. 0
+     * (default): a buffer is used in place only if the caller pinned it itself (hipHostMalloc / hipHostRegister); everything
+     * else gets pinned stand-ins or is copied through pageable transfers and is never registered. Why the caller has to say
+     * so: on ROCm 7, hipHostRegister / hipHostUnregister of a range that SHARES a page with other heap memory breaks the
+     * runtime's own on-the-fly pinning of pageable copy destinations on that page ("Memory access fault by GPU ... on address
+     * <heap address>", tools/debug/pageable_copy_stress.py reproduces it without this library) — and (round 5) a block that
+     * owns its pages but lies INSIDE the malloc heap (posix_memalign, an array that happens to be page-aligned) faults the
+     * same way once the heap around it is trimmed or reused while the GPU writes it
+     * (tools/debug/heap_interior_registration_stress.py); a mapping of its own never does. Rounds 3-4 registered any
+     * page-aligned whole-page buffer unasked; the library cannot tell the two kinds apart, so it no longer does. */
     int32_t host_pages_exclusive;
     /* How the device keeps the state (round 4; ADVICE r3: the choice is part of the handle's declared contract, not only of
      * its size). DRONE_LAYOUT_AUTO (0, default): hover / swarm handles whose step is HBM-bound (about 2^19 envs on) use the
@@ -198,9 +202,9 @@ void drone_vec_step_repeat(DroneVec* v, int k_steps, const float* actions, float
 /* Host handles: pin (and map) a host block the caller owns, on the handle's device, so that the kernel can access it in
  * place — K-major blocks of drone_vec_step_many / drone_vec_step_repeat that are pinned (this call, hipHostMalloc,
  * hipHostRegister) are read / written over PCIe directly, without device staging and copy commands (1 024 envs, K = 32:
- * 5.4 -> ~2 us per env step). Same page-ownership rule as DroneConfig.host_pages_exclusive: the block must start on a
- * 4 KiB boundary and either span whole pages or be vouched for (pages_exclusive = 1: its own mmap / posix_memalign block
- * padded to whole pages). Unpin before freeing the block. 0 / -1 (drone_last_error). */
+ * 5.4 -> ~2 us per env step). Same rule as DroneConfig.host_pages_exclusive: the block must start on a 4 KiB boundary AND
+ * be vouched for (pages_exclusive = 1: a mapping of its own — mmap, shm — padded to whole pages; not a block of the malloc
+ * heap, however aligned: round 5). Unpin before unmapping the block. 0 / -1 (drone_last_error). */
 int drone_vec_host_pin(DroneVec* v, void* block, size_t bytes, int pages_exclusive);
 /* Drops a registration drone_vec_host_pin made on this handle. A block host_pin found already pinned by its owner
  * (hipHostMalloc / the caller's own hipHostRegister) was never registered here and is left alone: returns 0. */

@@ -380,28 +380,30 @@ def test_rebinding_from_a_second_thread_while_another_handle_steps(oracle, hip):
 
 
 def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip, monkeypatch):
-    """Host buffers are registered (zero-copy transport) only when their pages are provably theirs; anything else is
-    never registered: the kernel gets pinned stand-ins owned by the library (small shards) or device mirrors. All cases
-    step bit-exactly."""
+    """Host buffers are registered (zero-copy transport) only when the CALLER vouches that each is a mapping of its own
+    (`host_pages_exclusive`; round 5: alignment alone no longer suffices — a page-aligned block inside the malloc heap faults
+    under GPU writes when the heap around it moves) or has pinned them itself; anything else is never registered: the kernel gets
+    pinned stand-ins owned by the library, or device mirrors. All cases step bit-exactly."""
     n, seed = 4096, 5  # 4096 envs: every buffer is a whole number of pages
     mk = lambda alloc: (alloc((n, 20), np.float32), alloc((n, 4), np.float32), alloc((n,), np.float32), alloc((n,), np.uint8), alloc((n,), np.uint8))
     heap = lambda s, d: np.zeros(s, d)
-    # (what, buffers, transport, stand-in budget, transport after the ACTION buffer is rebound to a fresh heap array)
-    cases = [("binding's own page buffers", None, "zero-copy", None, "mirror"),
-             ("caller's heap arrays (np.zeros): share pages with other allocations", mk(heap), "stand-in", None, "stand-in"),
-             ("the same with stand-ins turned off", mk(heap), "mirror", "0", "mirror"),
-             ("the same with a single-memcpy budget below this shard's 408 KiB: the host copy pool moves the stand-ins (round 5)", mk(heap), "stand-in-mt", "300000", "stand-in-mt"),
-             ("a PufferLib-style worker: page-owning observations / actions / rewards, heap flag slices",
+    # (what, buffers, transport, stand-in budget, transport after the ACTION buffer is rebound to a fresh heap array, caller vouches)
+    cases = [("binding's own page buffers", None, "zero-copy", None, "mirror", None),
+             ("caller's heap arrays (np.zeros): share pages with other allocations", mk(heap), "stand-in", None, "stand-in", 0),
+             ("the same with stand-ins turned off", mk(heap), "mirror", "0", "mirror", 0),
+             ("the same with a single-memcpy budget below this shard's 408 KiB: the host copy pool moves the stand-ins (round 5)", mk(heap), "stand-in-mt", "300000", "stand-in-mt", 0),
+             ("a PufferLib-style worker that vouches for its mappings: page-owning observations / actions / rewards, heap flag slices",
               (hip.page_buffer((n, 20), np.float32), hip.page_buffer((n, 4), np.float32), hip.page_buffer((n,), np.float32), np.zeros(n + 64, np.uint8)[64:], np.zeros(n + 64, np.uint8)[64:]),
-              "stand-in", None, "mirror"),  # its action buffer was mapped directly: replacing it ends the zero-copy transport
-             ("caller's page-aligned whole-page arrays, no flag", mk(hip.page_buffer), "zero-copy", None, "mirror")]
-    for what, bufs, want, budget, after_rebind in cases:
+              "stand-in", None, "mirror", 1),  # its action buffer was mapped directly: replacing it ends the zero-copy transport
+             ("caller's own mappings, vouched for", mk(hip.page_buffer), "zero-copy", None, "mirror", 1),
+             ("the same mappings WITHOUT the caller's word: page-aligned whole pages are no longer registered unasked (round 5)", mk(hip.page_buffer), "stand-in", None, "stand-in", 0)]
+    for what, bufs, want, budget, after_rebind, vouch in cases:
         if budget is None:
             monkeypatch.delenv("DRONE_HOST_BOUNCE_MAX_BYTES", raising=False)
         else:
             monkeypatch.setenv("DRONE_HOST_BOUNCE_MAX_BYTES", budget)
         o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(1, horizon=25), threads=4)
-        h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25), buffers=bufs) if bufs is not None else hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25))
+        h = hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25, host_pages_exclusive=vouch), buffers=bufs) if bufs is not None else hip.DroneVec(n, seed=seed, cfg=hip.default_config(1, horizon=25))
         assert h.host_transport == want, what
         o.reset(seed)
         h.reset(seed)

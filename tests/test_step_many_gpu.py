@@ -218,7 +218,10 @@ def test_host_blocks_pinned_and_not(oracle, hip):
     assert b"4 KiB" in h._f["drone_last_error"]()
     h.clear_status()
     ok = hip.page_buffer((4096,), np.uint8)
-    assert h._f["drone_vec_host_pin"](h._h, ok.ctypes.data, ok.nbytes, 0) == 0
+    # round 5: page-aligned whole pages are not enough — the caller must vouch that the block is a mapping of its own
+    assert h._f["drone_vec_host_pin"](h._h, ok.ctypes.data, ok.nbytes, 0) == -1 and b"vouched" in h._f["drone_last_error"]()
+    h.clear_status()
+    assert h._f["drone_vec_host_pin"](h._h, ok.ctypes.data, ok.nbytes, 1) == 0
     assert h._f["drone_vec_host_pin"](h._h, ok.ctypes.data, ok.nbytes, 0) == 0  # already pinned: fine
     assert h._f["drone_vec_host_unpin"](h._h, ok.ctypes.data) == 0
     assert_state_equal(o.get_state(), h.get_state(), "state")
