@@ -304,6 +304,38 @@ void copy_chunks(DroneVec* v, uint32_t c0, uint32_t c1) {
     if (v->bounce[3]) memcpy(v->u_term + r0, static_cast<const unsigned char*>(v->bounce[3]) + r0, r1 - r0);
     if (v->bounce[4]) memcpy(v->u_trunc + r0, static_cast<const unsigned char*>(v->bounce[4]) + r0, r1 - r0);
 }
+#ifndef DRONE_HOST_STAMPS
+#define DRONE_HOST_STAMPS 0  // diagnostic build: where a transport-3 step's microseconds go on the host (tools/host_timeline.py)
+#endif
+#if DRONE_HOST_STAMPS
+struct HostStamps {
+    enum { kEnter, kActionsIn, kLaunched, kPoolStarted, kFirstChunkSeen, kLastChunkCopied, kPoolFinished, kFlagSeen, kCount };
+    double sum[kCount] = {};
+    uint64_t steps = 0;
+    double t0 = 0, first_seen[64], last_done[64];
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+    void enter() { t0 = now(); for (int k = 0; k < 64; k++) { first_seen[k] = 1e300; last_done[k] = 0; } }
+    void at(int what) { sum[what] += now() - t0; }
+    void fold() {
+        double f = 1e300, l = 0;
+        for (int k = 0; k < 64; k++) { if (first_seen[k] < f) f = first_seen[k]; if (last_done[k] > l) l = last_done[k]; }
+        if (l > 0) { sum[kFirstChunkSeen] += f - t0; sum[kLastChunkCopied] += l - t0; }
+        steps++;
+    }
+    ~HostStamps() {
+        if (!steps) return;
+        static const char* names[kCount] = {"enter", "actions_in", "launched", "pool_started", "first_chunk_seen", "last_chunk_copied", "pool_finished", "flag_seen"};
+        fprintf(stderr, "[drone host stamps] %llu steps, us from entry:", (unsigned long long)steps);
+        for (int k = 1; k < kCount; k++) fprintf(stderr, " %s=%.2f", names[k], sum[k] / (double)steps);
+        fprintf(stderr, "\n");
+    }
+};
+HostStamps g_stamps;
+#define HOST_STAMP(what) g_stamps.at(HostStamps::what)
+#else
+#define HOST_STAMP(what) ((void)0)
+#endif
+
 // The step's outputs, while the kernel runs: this thread owns a contiguous share of the chunks and copies every run of
 // chunks whose words have turned to the step's sequence number. The words are an accelerator, not the contract: once the
 // calling thread has seen the stream drain (stream_idle) everything has landed and the rest is copied without looking.
@@ -321,9 +353,15 @@ void copy_outputs_part(void* ctx, int part, int parts) {
             else CopyPool::cpu_relax();
             continue;
         }
+#if DRONE_HOST_STAMPS
+        if (g_stamps.first_seen[part & 63] > 1e299) g_stamps.first_seen[part & 63] = HostStamps::now();
+#endif
         copy_chunks(v, c, e);
         c = e;
     }
+#if DRONE_HOST_STAMPS
+    g_stamps.last_done[part & 63] = HostStamps::now();
+#endif
 }
 
 bool host_to_device_actions(DroneVec* v) {
@@ -427,7 +465,13 @@ bool finish_host_outputs(DroneVec* v) {
     if (v->zero_copy) {  // outputs already landed in the caller's memory (or its stand-ins): just wait for the kernel
         if (v->copy_started) {  // transport 3, a step: the pool has been copying chunks out since the launch
             const bool ok = finish_threaded_copy(v);
-            return wait_zero_copy(v) && ok;
+            HOST_STAMP(kPoolFinished);
+            const bool landed = wait_zero_copy(v);
+            HOST_STAMP(kFlagSeen);
+#if DRONE_HOST_STAMPS
+            g_stamps.fold();
+#endif
+            return landed && ok;
         }
         if (!wait_zero_copy(v)) return false;
         if (v->threaded) {
@@ -1298,7 +1342,11 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
 
 namespace {
 bool step_send_impl(DroneVec* v) {
+#if DRONE_HOST_STAMPS
+    g_stamps.enter();
+#endif
     if (v->host_buffers && !host_to_device_actions(v)) return false;
+    HOST_STAMP(kActionsIn);
     LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     if (!peer_before_launch(v, &sig)) return false;
     const bool copy_out = v->host_buffers && v->zero_copy && v->threaded && v->h_flag;  // (without the completion flag the plain wait + whole copy is used)
@@ -1308,6 +1356,7 @@ bool step_send_impl(DroneVec* v) {
     }
     SweepTune::Pair* timing = v->tune ? tune_before_step(v) : nullptr;  // an HBM-bound handle still measuring its sweep order (may set dv.order for this launch)
     HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream, &sig), return false);
+    HOST_STAMP(kLaunched);
     if (timing && hipEventRecord(timing->e1, v->stream) != hipSuccess) {  // (v->tune is still there: a pair is only handed out while measuring)
         (void)hipGetLastError();
         timing->cand = -1;
@@ -1323,6 +1372,7 @@ bool step_send_impl(DroneVec* v) {
         __atomic_store_n(&v->stream_idle, 0, __ATOMIC_RELEASE);
         __atomic_store_n(&v->copy_abort, 0, __ATOMIC_RELEASE);
         v->copy_started = CopyPool::get().try_start(copy_outputs_part, v);  // (busy with another handle's step: this one's outputs are copied after the wait, by this thread)
+        HOST_STAMP(kPoolStarted);
     }
     return true;
 }
