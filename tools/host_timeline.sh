@@ -9,8 +9,8 @@ make -s -C drone_amd/csrc -B OUT=/tmp/hs/libdrone_hip.so EXTRA=-DDRONE_HOST_STAM
 for n in 16384 32768 65536 131072; do
   for rep in 1 2; do
     echo "== envs $n rep $rep" >> $O/timeline.txt
-    host/drone_host --envs $n --steps 2000 --fill 0 --heap 0 2>&1 | grep -v amdgpu.ids | tail -n 1 | cut -c1-200 >> $O/timeline.txt
-    LD_PRELOAD=/tmp/hs/libdrone_hip.so host/drone_host --envs $n --steps 2000 --fill 0 --heap 1 2>&1 | grep -v amdgpu.ids | tail -n 2 | cut -c1-400 >> $O/timeline.txt
+    host/drone_host --envs $n --steps 2000 --fill 0 --heap 0 2>&1 | grep -v amdgpu.ids | grep per-step | cut -c1-260 >> $O/timeline.txt
+    LD_PRELOAD=/tmp/hs/libdrone_hip.so host/drone_host --envs $n --steps 2000 --fill 0 --heap 1 2>&1 | grep -v amdgpu.ids | grep -E 'per-step|host stamps' | cut -c1-400 >> $O/timeline.txt
   done
 done
 cat $O/timeline.txt
