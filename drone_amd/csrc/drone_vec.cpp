@@ -1191,7 +1191,12 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         // mirror transport's DMA copies are as good); DRONE_HOST_COPY_THREADS=1 (no pool) keeps the mirror transport.
         const char* mm = getenv("DRONE_HOST_MT_MAX_BYTES");
         const size_t mt_max = (mm && *mm) ? (size_t)atoll(mm) : ((size_t)64 << 20);
-        const bool threaded = bounce_max > 0 && unpinned_bytes > bounce_max && unpinned_bytes <= mt_max && CopyPool::get().parts() > 1;  // (a budget of 0 turns stand-ins of either kind off)
+        // Where the pool takes over from the single memcpy: DRONE_HOST_POOL_MIN_BYTES, default 512 KiB (~5 000 hover envs; measured at
+        // equal cost at 4 096 envs, 36 against 40 us at 6 144, 39 against 54 at 8 192: profiles/r05_ab/pool_hand_over.txt) — the single
+        // memcpy stays the fallback up to DRONE_HOST_BOUNCE_MAX_BYTES in a process without the pool; a budget set by hand moves both.
+        const char* pm = getenv("DRONE_HOST_POOL_MIN_BYTES");
+        const size_t pool_min = (pm && *pm) ? (size_t)atoll(pm) : (bm && *bm) ? bounce_max : ((size_t)512 << 10);
+        const bool threaded = bounce_max > 0 && unpinned_bytes > pool_min && unpinned_bytes <= mt_max && CopyPool::get().parts() > 1;  // (a budget of 0 turns stand-ins of either kind off)
         if (want_zero_copy(num_envs) && (unpinned_bytes <= bounce_max || threaded)) {
             void* mapped[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             bool have_all = true;

@@ -132,10 +132,11 @@ const char* drone_vec_variant(const DroneVec* v);
 
 /* How host-buffer steps of this handle move their data: 1 = zero-copy (the kernel reads / writes the caller's pinned
  * buffers over PCIe); 2 = zero-copy through pinned stand-ins the library owns for those of the five buffers that could
- * not be pinned themselves, copied to / from the caller's memory on the host around each step (small shards only:
- * DRONE_HOST_BOUNCE_MAX_BYTES, default 1 MiB of such buffers); 3 (round 5) = the same stand-ins for mid-size shards (up to
+ * not be pinned themselves, copied to / from the caller's memory on the host around each step (small shards only: up to
+ * DRONE_HOST_POOL_MIN_BYTES, default 512 KiB of such buffers — DRONE_HOST_BOUNCE_MAX_BYTES, default 1 MiB, in a process
+ * without the pool); 3 (round 5) = the same stand-ins for mid-size shards (up to
  * DRONE_HOST_MT_MAX_BYTES, default 64 MiB of unpinnable buffers — a vec-env worker's unaligned shared-memory slices at
- * 16 384 ... ~10^5 envs), moved by a small pool of host threads (DRONE_HOST_COPY_THREADS per job, caller included; default
+ * 5 000 ... ~10^5 envs), moved by a small pool of host threads (DRONE_HOST_COPY_THREADS per job, caller included; default
  * half the machine's hardware threads, at most 8; 1 = off): the action rows go in as parallel slices, and the outputs come out WHILE the step kernel is still writing
  * over PCIe — each 256-drone chunk as soon as its workgroup says its rows have landed. The pool is one per process, started
  * on first use; its threads spin for ~200 us after a job and sleep otherwise; it serves one handle at a time (from

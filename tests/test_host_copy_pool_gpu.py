@@ -124,7 +124,28 @@ def test_without_a_pool_such_shards_take_the_mirror_transport():
     """DRONE_HOST_COPY_THREADS=1 is read when the process-wide pool starts: a process of its own."""
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
             "import numpy as np\nfrom drone_amd import binding\nfrom test_host_copy_pool_gpu import heap_buffers\n"
-            "h = binding.DroneVec(16384, seed=1, task=0, buffers=heap_buffers(16384, 20))\nprint('TRANSPORT', h.host_transport)\nh.reset(1); h.step(); h.close()\n")
+            "h = binding.DroneVec(16384, seed=1, task=0, buffers=heap_buffers(16384, 20))\nprint('TRANSPORT', h.host_transport)\nh.reset(1); h.step(); h.close()\n"
+            # between the pool's hand-over (512 KiB of unpinnable buffers) and the single memcpy's own budget (1 MiB): one memcpy, as before the pool
+            "h = binding.DroneVec(8192, seed=1, task=0, buffers=heap_buffers(8192, 20))\nprint('TRANSPORT8192', h.host_transport)\nh.reset(1); h.step(); h.close()\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, DRONE_HOST_COPY_THREADS="1"))
     assert r.returncode == 0, r.stderr[-1500:]
-    assert "TRANSPORT mirror" in r.stdout, r.stdout
+    assert "TRANSPORT mirror" in r.stdout and "TRANSPORT8192 stand-in\n" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("n,want", [(4096, "stand-in"), (5000, "stand-in"), (6144, "stand-in-mt"), (8192, "stand-in-mt")])
+def test_where_the_pool_takes_over_from_the_single_memcpy(hip, oracle, n, want):
+    """DRONE_HOST_POOL_MIN_BYTES, default 512 KiB of unpinnable buffers (102 B per hover env): measured at equal cost at
+    4 096 envs and 1.4x ahead at 8 192 (profiles/r05_ab/pool_hand_over.txt). Both sides of it bit for bit."""
+    seed = 5
+    h = hip.DroneVec(n, seed=seed, task=0, buffers=heap_buffers(n, 20), horizon=20)
+    assert h.host_transport == want
+    o = oracle.OracleVec(n, seed=seed, cfg=oracle.default_config(0, horizon=20), threads=8)
+    o.reset(seed)
+    h.reset(seed)
+    for t in range(45):
+        o.fill_random_actions()
+        h.actions[:] = o.actions
+        o.step()
+        h.step()
+        assert_outputs_equal(o, h, f"step {t}")
+    h.close()
