@@ -10,7 +10,7 @@
 //
 // One pool per process, started on first use. Workers spin for a short while after a job (a vec-env steps every few
 // hundred microseconds: a futex wake-up would cost a tenth of the step) and sleep on a condition variable when the
-// handle goes quiet. One job at a time (a mutex held from try_start() to finish()): whoever finds the pool busy does its
+// handle goes quiet. One job at a time (a flag held from try_start() to finish()): whoever finds the pool busy does its
 // copying alone, on its own thread. Nothing here touches HIP.
 #pragma once
 
@@ -40,7 +40,7 @@ public:
     // false: the pool is busy with another job (another handle between its step_send and step_recv, possibly on this very
     // thread — waiting could never end): nothing was started, the caller does the work by itself, fn(ctx, 0, 1).
     bool try_start(Fn fn, void* ctx) {
-        if (!busy_.try_lock()) return false;
+        if (busy_.exchange(true, std::memory_order_acquire)) return false;
         fn_ = fn;
         ctx_ = ctx;
         done_.store(0, std::memory_order_relaxed);
@@ -61,7 +61,7 @@ public:
             if (watch && (spins++ & 255u) == 0) watch(watch_ctx);
             cpu_relax();
         }
-        busy_.unlock();
+        busy_.store(false, std::memory_order_release);
     }
     void run(Fn fn, void* ctx) {
         if (try_start(fn, ctx)) finish();
@@ -123,7 +123,8 @@ private:
     }
 
     std::vector<std::thread> workers_;
-    std::mutex busy_, m_;
+    std::atomic<bool> busy_{false};  // a flag, not a mutex: drone_vec_step_send and drone_vec_step_recv may come from different threads, and a mutex belongs to the thread that locked it
+    std::mutex m_;
     std::condition_variable cv_;
     std::atomic<unsigned> gen_{0};
     std::atomic<int> done_{0}, sleepers_{0};
