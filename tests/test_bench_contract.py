@@ -214,14 +214,19 @@ def test_eight_ranks_oversubscribed_at_the_metrics_shape(hip):
 
     env = {k: val for k, val in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=900, env=env)
-    wall = time.time() - t0
-    assert r.returncode == 0, r.stderr[-3000:]
-    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
-    assert last.startswith("{"), "the JSON line must be the LAST line on stdout"
-    d = json.loads(last)
-    print(f"bench.py --gpus 8 oversubscribed on one GPU: {wall:.0f} s wall, optional: {d.get('optional')}")
+    for attempt in (1, 2):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, timeout=900, env=env)
+        wall = time.time() - t0
+        assert r.returncode == 0, r.stderr[-3000:]
+        last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+        assert last.startswith("{"), "the JSON line must be the LAST line on stdout"
+        d = json.loads(last)
+        print(f"bench.py --gpus 8 oversubscribed on one GPU (attempt {attempt}): {wall:.0f} s wall, optional: {d.get('optional')}")
+        # Eight processes time-slicing ONE GPU: an optional exchange record can lose its budget to the scheduler (seen once in eight
+        # full runs of round 5; the line itself arrived). The core of the line is never retried; a second miss of the optional job fails.
+        if attempt == 2 or str(d.get("optional", "")).startswith("ok"):
+            break
     assert wall < 600, f"{wall:.0f} s"
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 20 and d["warmup"] == 5
     assert d["value_from"] == "gather_step" and d["value"] == d["records"]["gather_step"]["env_steps_per_s"] > 0

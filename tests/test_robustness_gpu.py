@@ -2,11 +2,15 @@
 rollouts, checkpoint restore with the step counter, the sticky status of the
 void path calls, the caller's current device, the index-range check, and the
 RCCL gather reached through the C-ABI (one rank on the 1-GPU box)."""
+import os
+
 import numpy as np
 import pytest
 
 from drone_amd import abi
 from helpers import assert_bits_equal, assert_outputs_equal, assert_state_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -450,35 +454,52 @@ def test_only_buffers_that_own_their_pages_are_pinned(oracle, hip, monkeypatch):
     monkeypatch.delenv("DRONE_HOST_MT_MAX_BYTES")
 
 
-def test_host_handles_beside_pageable_copies_do_not_fault(hip):
+_PAGEABLE_STRESS = r"""
+import sys, time
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from drone_amd import binding as hip
+rng = np.random.default_rng(0)
+dev = [torch.randn(k, device="cuda") for k in (5000, 60000, 400000, 1 << 20)]
+keep = []
+t0 = time.time()
+it = 0
+while time.time() - t0 < 12.0:
+    it += 1
+    n = int(rng.integers(64, 3000))
+    bufs = (np.zeros((n, 20), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
+    h = hip.DroneVec(n, seed=it, cfg=hip.default_config(0), buffers=bufs)
+    h.reset(it)
+    h.step()
+    x = dev[it % 4].cpu()
+    y = np.empty(int(rng.integers(1000, 2_000_000)), np.float32)
+    y[: min(len(y), x.numel())] = x.numpy()[: min(len(y), x.numel())]
+    h.close()
+    keep.append(y)
+    if len(keep) > int(rng.integers(1, 40)):
+        keep.clear()
+torch.cuda.synchronize()
+print("ITERATIONS", it, flush=True)
+"""
+
+
+def test_host_handles_beside_pageable_copies_do_not_fault(hip, tmp_path):
     """Regression for the ROCm interaction that killed ~1 in 12 runs of this suite ("Memory access fault by GPU ... on
     address <heap address>"): hipHostRegister / hipHostUnregister of heap buffers that share pages with other
     allocations, beside the runtime's own on-the-fly pinning of pageable copy destinations (torch .cpu()). Host handles
     over plain heap arrays are created, stepped and closed in a loop with pageable copies in between; since such
     buffers are no longer registered the loop must survive (tools/debug/pageable_copy_stress.py is the library-free
-    reproducer: it faults within seconds in 'reg' mode and never in 'reg_aligned' mode)."""
-    import time
+    reproducer: it faults within seconds in 'reg' mode and never in 'reg_aligned' mode).
+    In a process of its own (round 5): a GPU memory fault is an abort() inside the HSA runtime, which took the whole pytest
+    session — and its captured message — with it the one time it happened here (once in eight full runs of the round, not
+    reproduced in ten repetitions of this test nor by 138 000 pinned allocations beside pageable copies,
+    tools/debug/heap_interior_registration_stress.py hostmalloc); now it would be this test's failure, with the message."""
+    import subprocess
+    import sys
 
-    import torch
-
-    rng = np.random.default_rng(0)
-    dev = [torch.randn(k, device="cuda") for k in (5000, 60000, 400000, 1 << 20)]
-    keep = []
-    t0 = time.time()
-    it = 0
-    while time.time() - t0 < 12.0:
-        it += 1
-        n = int(rng.integers(64, 3000))
-        bufs = (np.zeros((n, 20), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.zeros(n, np.uint8))
-        h = hip.DroneVec(n, seed=it, cfg=hip.default_config(0), buffers=bufs)
-        h.reset(it)
-        h.step()
-        x = dev[it % 4].cpu()
-        y = np.empty(int(rng.integers(1000, 2_000_000)), np.float32)
-        y[: min(len(y), x.numel())] = x.numpy()[: min(len(y), x.numel())]
-        h.close()
-        keep.append(y)
-        if len(keep) > int(rng.integers(1, 40)):
-            keep.clear()
-    torch.cuda.synchronize()
+    script = tmp_path / "pageable_stress.py"
+    script.write_text(_PAGEABLE_STRESS.format(root=ROOT))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    it = int(r.stdout.split("ITERATIONS")[1].split()[0])
     assert it > 100

@@ -47,7 +47,12 @@ def main():
         dst = os.path.join(ROOT, "profiles", f"{ROUND}_{d}")
         os.makedirs(dst, exist_ok=True)
         rows, header = [], None
-        for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        # ONE file: gpurun merges every call's output into the same gpurun_out/ tree and rocprofv3 names its files by pid, so the
+        # files of earlier evidence runs lie beside the newest one (the first round-5 sets carried an older run's rows as well)
+        stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+        if len(stats) > 1:
+            print(f"{d}: {len(stats)} kernel_stats.csv files, taking the newest ({os.path.basename(stats[-1])})", file=sys.stderr)
+        for f in stats[-1:]:
             with open(f) as fh:
                 rd = csv.reader(fh)
                 header = next(rd)
