@@ -37,6 +37,7 @@ def test_every_profile_names_its_kernels_consistently(isa_kernels):
         with open(os.path.join(d, "kernel_stats.csv")) as fh:
             rows = list(csv.DictReader(fh))
         assert [r["Name"] for r in rows] == [k["name"] for k in s["kernels"]], d
+        assert len({r["Name"] for r in rows}) == len(rows), f"{d}: a kernel listed twice — rows of two profile runs in one table"
         for r, k in zip(rows, s["kernels"]):
             assert float(r["AverageNs"]) / 1e3 == pytest.approx(k["avg_us"]) and int(r["Calls"]) == k["calls"], (d, k["name"])
             assert k["mangled"] in isa_kernels, f"{d}: {k['name']} is not a kernel of the current sources — stale profile"
