@@ -54,8 +54,6 @@ struct LaunchSig {
     uint32_t* arrive;      // HBM: workgroups of this launch that have released their stores; zero between launches
     uint32_t* wg_done;     // pinned host memory (device-mapped): [chunks] words, or null
     uint32_t ack_value, post_value, wg_done_value;
-    const uint32_t* stop;  // HBM word a stream-side wait of this handle raises when it gives up (a dead peer), or null: a launch
-                           // that finds it raised stores nothing and publishes nothing (no rows into the root's batch behind a failed wait)
 };
 
 #ifndef DRONE_BLOCK  // workgroup size (tuning knob; multiple of 64)
@@ -85,6 +83,6 @@ hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid
 // handle gave up: the waits a caller has queued behind it must not spin their budgets one after the other).
 // ONE launch for all the ranks waited for.
 hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s);
-hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, uint32_t* stop, unsigned long long budget_ticks, hipStream_t s);
+hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s);
 
 }  // namespace drone

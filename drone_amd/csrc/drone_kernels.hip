@@ -590,11 +590,6 @@ __device__ __forceinline__ void advance_counters(const StepArgs& a, const Counte
 // Peer-store exchange: the handshake's two publications from inside the launch that writes the outputs (LaunchSig).
 // ack: the root's stream has reached this launch, so whatever consumed the previous batch is done (stream order); one
 // relaxed system-scope store by the first lane of the grid — it carries no data, so no fence.
-// a stream-side wait of this handle has given up (LaunchSig::stop): the handshake is broken — the root may still be reading the
-// batch this launch would overwrite, or nobody is left to read it. Launch-uniform; a null pointer (no exchange) costs a scalar test.
-__device__ __forceinline__ bool peer_stopped(const StepArgs& a) {
-    return a.sig.stop && __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.sig.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u;
-}
 __device__ __forceinline__ void peer_ack(const StepArgs& a) {
     if (a.sig.ack_flag && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(a.sig.ack_flag, a.sig.ack_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -727,7 +722,6 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
     __builtin_amdgcn_sched_barrier(0);
 #endif
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
-    if (peer_stopped(a)) return;
     peer_ack(a);
 #pragma unroll
     for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
@@ -841,7 +835,6 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t block_base = blockIdx.x * kBlock;
     const uint32_t i = block_base + threadIdx.x;
-    if (peer_stopped(a)) return;
     peer_ack(a);
     Lane L;
     L.episode = 0u;
@@ -917,7 +910,7 @@ struct PrioRotor {
 #define DRONE_ROLLOUT_WAVES
 #endif
 
-template <int TASK, bool PK, bool STOP = false>  // STOP: the handle is in a peer-store exchange (LaunchSig::stop) — an instantiation of its own, so that every other rollout is instruction for instruction what it was
+template <int TASK, bool PK>
 __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(StepArgs a, uint32_t horizon, uint32_t prio_mod) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -933,11 +926,6 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
-    // LaunchSig::stop: loaded here, beside the state, and looked at behind the step loop — an early exit up here waits for this
-    // load before the first instruction of the loop, in every wave of the launch (+2.5 % at 2^20 envs; behind the loop still +0.5 %, hence the
-    // instantiation of its own: profiles/r05_ab/ab_stop_rollout_*.txt)
-    uint32_t stop_word = 0u;
-    if (STOP) stop_word = __hip_atomic_load(a.sig.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     peer_ack(a);
     float rsum = 0.0f;
     bool any_term = false, any_trunc = false, any_target = false;
@@ -971,7 +959,6 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
         row[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
-    if (STOP && __builtin_amdgcn_readfirstlane(stop_word) != 0u) return;  // a wait of this handle gave up before this launch: nothing is stored or published
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
     store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)), dt);
     out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], rsum);
@@ -1202,7 +1189,7 @@ __global__ __launch_bounds__(64) void drone_flag_post_kernel(uint32_t* flag, uin
 // peer), and a caller that does not sync every launch has queued every later step's wait behind it — each would
 // otherwise spin its full budget in turn. The error word is loaded together with the flags (both live in
 // host memory: one PCIe round trip either way).
-__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, uint32_t* stop, unsigned long long budget_ticks) {
+__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         const uint32_t failed = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1211,10 +1198,7 @@ __global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* fla
             if (r != skip) ok = ok && (int32_t)(__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0;
         if (__all(ok) || failed != 0u) break;  // wave-uniform (err is one address: every lane read the same word)
         if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the launches queued behind this wait read it from HBM (the kernel boundary publishes it)
-            }
+            if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         __builtin_amdgcn_s_sleep(64);
@@ -1227,7 +1211,7 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     a.gstep = gstep;
     a.done_slot = 0;
     a.nwg = 0;  // set by the launchers that deal chunks (step, rollout, step_many)
-    a.sig = LaunchSig{nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr};
+    a.sig = LaunchSig{nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
 #if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
     a.kp = *v.kp_host;
@@ -1312,12 +1296,7 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     a.nwg = g.x;
     const bool pk = use_packed(v);
     const uint32_t prio_mod = resident_waves_per_simd(g.x, 4u);  // (every rollout instantiation takes 104-128 VGPRs: four waves per SIMD)
-    const bool st = a.sig.stop != nullptr;
-#define DRONE_LAUNCH_ROLLOUT(T)                                                                                                                \
-    do {                                                                                                                                       \
-        if (st) { if (pk) drone_rollout_kernel<T, true, true><<<g, b, 0, s>>>(a, horizon, prio_mod); else drone_rollout_kernel<T, false, true><<<g, b, 0, s>>>(a, horizon, prio_mod); } \
-        else { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon, prio_mod); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon, prio_mod); }               \
-    } while (0)
+#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon, prio_mod); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon, prio_mod); } while (0)
     if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_HOVER);
     else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_SWARM);
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_RACE);
@@ -1364,9 +1343,9 @@ hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, uint32_t* stop, unsigned long long budget_ticks, hipStream_t s) {
+hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s) {
     drop_stale_error();
-    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flags, count, skip, want, err, stop, budget_ticks);
+    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flags, count, skip, want, err, budget_ticks);
     return hipGetLastError();
 }
 

@@ -700,7 +700,6 @@ struct Gather {
     bool gpu_waits = true;               // the handshake runs on the stream (two one-wave kernels); false (DRONE_PEER_HOST_WAIT=1): the host drains the stream and polls / stores
     uint32_t* h_err = nullptr;           // pinned + mapped word a stream-side wait sets when it gave up (a dead peer)
     uint32_t* d_err = nullptr;
-    uint32_t* d_stop = nullptr;          // HBM twin of the error word: what the launches queued behind a failed wait read (LaunchSig::stop)
     unsigned long long budget_ticks = 0; // of the 100 MHz real-time counter
     uint32_t seq = 0;                    // rounds this rank has published (non-root) / collected (root)
     uint32_t acked = 0;                  // root: last round whose consumption it has announced
@@ -742,7 +741,6 @@ void gather_destroy(DroneVec* v) {
             if (g->peer_base[k]) (void)hipIpcCloseMemHandle(g->peer_base[k]);
         if (g->flags_registered) host_unregister(const_cast<uint32_t*>(g->flags), v, "peer-store flag page");
         if (g->h_err) (void)hipHostFree(g->h_err);
-        if (g->d_stop) (void)hipFree(g->d_stop);
         if (g->d_arrive) (void)hipFree(g->d_arrive);
         // the export is consumed: a later drone_vec_gather_init_peer needs a fresh drone_vec_gather_peer_export (ADVICE r4:
         // stale pointers here would be reused for buffers the caller may have freed since)
@@ -781,7 +779,7 @@ long peer_timeout_ms() {
 // flags [first, first + count) except `skip` (-1: none) have all reached `want`
 bool peer_wait_ge(DroneVec* v, Gather* g, int first, int count, int skip, uint32_t want) {
     if (g->gpu_waits) {  // one launch, one lane per flag, polling the shared words from the stream; gives up after the budget and says so in *d_err
-        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags) + first, (uint32_t)count, (uint32_t)skip, want, g->d_err, g->d_stop, g->budget_ticks, v->stream), return false);
+        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags) + first, (uint32_t)count, (uint32_t)skip, want, g->d_err, g->budget_ticks, v->stream), return false);
         return true;
     }
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
@@ -846,7 +844,6 @@ bool peer_before_launch(DroneVec* v, LaunchSig* sig) {
     Gather* g = v->gather;
     if (!g || !g->peer) return true;
     const bool in_kernel = g->in_kernel && g->gpu_waits && !g->stream_writes;
-    sig->stop = g->d_stop;  // (null with host-side waits: those fail the call itself)
     if (g->rank != g->root) {
         g->launch_posts = 0;
         if (in_kernel) {
@@ -1342,7 +1339,7 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
     v->list_valid = false;
     v->many_k = 0;
-    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr};
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     if (!upload_params(v) || !push_counters(v) || !peer_before_launch(v, &sig)) return;
     HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream, &sig), return);
     if (v->host_buffers) device_to_host_outputs(v);
@@ -1355,7 +1352,7 @@ bool step_send_impl(DroneVec* v) {
 #endif
     if (v->host_buffers && !host_to_device_actions(v)) return false;
     HOST_STAMP(kActionsIn);
-    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr};
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     if (!peer_before_launch(v, &sig)) return false;
     const bool copy_out = v->host_buffers && v->zero_copy && v->threaded && v->h_flag;  // (without the completion flag the plain wait + whole copy is used)
     if (copy_out) {
@@ -1410,7 +1407,7 @@ void drone_vec_rollout(DroneVec* v, int horizon) {
     Entry in(v);
     if (!in || !idle(v, "rollout")) return;
     if (horizon <= 0) { set_err("rollout: horizon must be positive, got %d", horizon); return; }
-    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr};
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     if (!peer_before_launch(v, &sig)) return;
     HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream, &sig), return);
     v->gstep += (uint32_t)horizon;
@@ -2116,8 +2113,6 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
         *g->h_err = 0u;
         g->d_err = static_cast<uint32_t*>(mapped_ptr(he));
         if (!g->d_err) { set_err("gather_init_peer: the error word could not be mapped"); gather_destroy(v); return -1; }
-        HIP_TRY(hipMalloc((void**)&g->d_stop, 64), { gather_destroy(v); return -1; });
-        HIP_TRY(hipMemsetAsync(g->d_stop, 0, 64, v->stream), { gather_destroy(v); return -1; });
         g->budget_ticks = (unsigned long long)peer_timeout_ms() * 100000ull;  // s_memrealtime counts at 100 MHz
     }
     const size_t od = (size_t)drone_obs_dim(v->cfg.task), o = g->offsets[rank];

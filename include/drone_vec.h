@@ -335,10 +335,8 @@ void drone_vec_gather_close(DroneVec* v);
  * stale round. drone_vec_gather_close gives the handle its own output buffers back and forgets the export (export again
  * before another drone_vec_gather_init_peer). A dead peer: every wait gives up after DRONE_PEER_TIMEOUT_MS (default
  * 10 000; clamped to 1 ... 600 000, anything else is the default) — a stream-side wait raises a flag that fails the next
- * call on the handle, makes every wait already queued behind it return at once, and makes every reset / step / rollout
- * launch already queued behind it store and publish NOTHING (the root, perhaps only slow, may still be reading the rows
- * such a launch would overwrite; the handle's state is then behind its step counter: it is in error and stays so);
- * DRONE_PEER_HOST_WAIT=1 moves the whole
+ * call on the handle and makes every wait already queued behind it return at once (the launches queued behind it still
+ * run and store their rows: after such an error the root's batch is not to be trusted); DRONE_PEER_HOST_WAIT=1 moves the whole
  * handshake to the host (the stream is drained, the host polls / stores), where the timeout is an immediate error. */
 #define DRONE_PEER_TOKEN_BYTES 288
 int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* all_rewards,
