@@ -81,3 +81,21 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 code = "\n".join(l for l in text.splitlines() if not l.strip().startswith(("#", "//", "*", "/*", '"""')))
                 assert not re.search(r"(import|from)\s+oracle|include\s+[\"<].*oracle|liboracle|libdrone_oracle", code), os.path.join(dirpath, f)
+
+
+def test_every_environment_knob_is_documented():
+    """Every DRONE_* variable the library reads is a row of INTEGRATION.md's table (and the table lists nothing the
+    library does not read): a knob that changes which transport, kernel variant or handshake a handle gets is part of
+    the boundary's behaviour."""
+    import glob
+    import re
+
+    read = set()
+    for path in glob.glob(os.path.join(ROOT, "drone_amd", "csrc", "*")):
+        if path.endswith((".cpp", ".hip", ".hpp", ".h")):
+            read |= set(re.findall(r'getenv\("(DRONE_[A-Z0-9_]+)"\)', open(path).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## Environment variables `libdrone_hip.so` reads"):]
+    listed = set(re.findall(r"^\| `(DRONE_[A-Z0-9_]+)` \|", table, re.M))
+    assert read - listed == set(), f"read by the library, missing from INTEGRATION.md: {sorted(read - listed)}"
+    assert listed - read == set(), f"documented, but nothing reads them: {sorted(listed - read)}"
