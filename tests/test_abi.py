@@ -99,3 +99,14 @@ def test_every_environment_knob_is_documented():
     listed = set(re.findall(r"^\| `(DRONE_[A-Z0-9_]+)` \|", table, re.M))
     assert read - listed == set(), f"read by the library, missing from INTEGRATION.md: {sorted(read - listed)}"
     assert listed - read == set(), f"documented, but nothing reads them: {sorted(listed - read)}"
+
+
+def test_every_entry_point_is_named_in_the_integration_guide():
+    """include/drone_vec.h declares the boundary; INTEGRATION.md is where a PufferLib maintainer reads what each entry
+    point replaces. None may be missing there."""
+    import re
+
+    header = open(os.path.join(ROOT, "include", "drone_vec.h")).read()
+    declared = set(re.findall(r"\b(drone_[a-z_0-9]+)\s*\(", header))
+    guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert {s for s in declared if s not in guide} == set()
