@@ -93,7 +93,7 @@ def test_the_bench_lines_roofline_is_reproduced_by_the_profile():
     assert "dt=1" in big and "autotuned=1" in big and any(f" order={o} " in big for o in (0, 6, 8)) and "<0, false," in k["name"] and "true>" in k["name"].split("(HIP_vector_type")[0]
     assert "mem=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, 0, true>" in k2["name"]
     # the driver's 20-step window (--steps 20 --warmup 5 behind the 150-step pre-roll) describes the same kernel state as the
-    # profile: its ms_per_step within a few per cent of rocprofv3's average at the metric's size
+    # profile: its ms_per_step within 2 % of rocprofv3's average at the metric's size
     drv = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_driver_window.json")))
     assert drv["steps"] == 20 and drv["warmup"] == 5 and drv["pre_roll_steps"] == 512 and drv["episodes_in_timed_window"] > 0
-    assert drv["ms_per_step"] * 1e3 == pytest.approx(k2["avg_us"], rel=0.05), (drv["ms_per_step"] * 1e3, k2["avg_us"])
+    assert drv["ms_per_step"] * 1e3 == pytest.approx(k2["avg_us"], rel=0.02), (drv["ms_per_step"] * 1e3, k2["avg_us"])
