@@ -667,9 +667,12 @@ static PyObject* vec_device(PyObject* self, PyObject* args) {
     return PyLong_FromLong(drone_vec_device(h->v));
 }
 
-/* vec_host_pin(handle, buffer, pages_exclusive=0) / vec_host_unpin(handle, buffer): pin a page-owning host block (any object
- * with a writable C-contiguous buffer, e.g. a numpy array over its own mmap) so that vec_step_many / vec_step_repeat access
- * it in place. The caller keeps the object alive and unpins it before letting it go. */
+/* vec_host_pin(handle, buffer, pages_exclusive) / vec_host_unpin(handle, buffer): pin a page-owning host block (any object
+ * with a writable C-contiguous buffer over a mapping of its own: a numpy array over its own mmap, a shared-memory block) so
+ * that vec_step_many / vec_step_repeat access it in place. pages_exclusive = 1 is the caller's word that the block is such
+ * a mapping (round 5: a page-aligned block inside the malloc heap must not be registered, and the library cannot tell);
+ * left at its default 0 the call fails with that explanation unless the block is already pinned. The caller keeps the
+ * object alive and unpins it before letting it go. */
 static PyObject* host_pin_impl(PyObject* args, int pin) {
     PyObject *cap, *buf;
     int excl = 0;
@@ -746,7 +749,7 @@ static PyMethodDef methods[] = {
     {"vec_fill_random_actions", vec_fill_random_actions, METH_VARARGS, "vec_fill_random_actions(handle, actions=None, gstep=None)"},
     {"vec_gstep", vec_gstep, METH_VARARGS, "vec_gstep(handle) -> int"},
     {"vec_device", vec_device, METH_VARARGS, "vec_device(handle) -> HIP device ordinal the env lives on"},
-    {"vec_host_pin", vec_host_pin, METH_VARARGS, "vec_host_pin(handle, buffer, pages_exclusive=0): pin a page-owning host block for in-place access by vec_step_many"},
+    {"vec_host_pin", vec_host_pin, METH_VARARGS, "vec_host_pin(handle, buffer, pages_exclusive): pin a host block that is a mapping of its own (pages_exclusive=1 vouches for that) for in-place access by vec_step_many"},
     {"vec_host_unpin", vec_host_unpin, METH_VARARGS, "vec_host_unpin(handle, buffer)"},
     {"vec_variant", vec_variant, METH_VARARGS, "vec_variant(handle) -> which per-step kernel instantiation and launch choices the env uses, as text (drone_vec_variant)"},
     {"vec_host_transport", vec_host_transport, METH_VARARGS, "vec_host_transport(handle) -> 0 mirror, 1 zero-copy, 2 zero-copy through pinned stand-ins, 3 the same moved by the host copy pool, -1 device buffers"},
