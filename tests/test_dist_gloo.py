@@ -64,7 +64,7 @@ def _root_worker(rank, world, port, total, steps, task, root, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total,root", [(2, 256, 0), (2, 257, 1), (3, 1000, 2)])
+@pytest.mark.parametrize("world,total,root", [(2, 256, 0), (2, 257, 1), (3, 1000, 2), (8, 1029, 5)])  # the last: eight ranks, ragged shards (129 / 128 envs), a root in the middle
 def test_gather_to_root_equals_single_vec(oracle, world, total, root):
     """RootGather on gloo: equal and ragged shards, first / last rank as the root; the root's batch is one oracle run's."""
     steps, task = 40, 1
