@@ -66,26 +66,6 @@
 #define DRONE_STEP_MAX_WAVES 0
 #endif
 
-#ifndef DRONE_STEP_TILES  // 256-drone chunks per workgroup of the per-step kernel, software-pipelined: the loads of chunk k+1 are in flight while chunk k computes. Measured SLOWER (+13 % at 2^20 with 2, ab_tiles_*): kept as the negative result
-#define DRONE_STEP_TILES 1
-#endif
-
-#ifndef DRONE_STEP_WAVE_OUTPUTS  // 1: full workgroups of the per-step kernel write their outputs per WAVE (write_outputs_wave: no LDS masks, no workgroup barrier, 64-byte flag pieces) like the K-steps kernel; 0: per workgroup (256-byte flag pieces behind one barrier)
-#define DRONE_STEP_WAVE_OUTPUTS 0
-#endif
-#ifndef DRONE_LOG_FOLD_LATE  // 1: the log-plane read-modify-write of an ended episode completes at the very end of the chunk; 0: right after the state stores
-#define DRONE_LOG_FOLD_LATE 1
-#endif
-
-// MEASUREMENT ONLY (results are wrong with either): drop the log-plane read-modify-write / the target-plane rewrite
-// of ended episodes, to price those scattered 16-byte accesses (tools/ab_step.py)
-#ifndef DRONE_EXP_NO_LOG
-#define DRONE_EXP_NO_LOG 0
-#endif
-#ifndef DRONE_EXP_NO_PT
-#define DRONE_EXP_NO_PT 0
-#endif
-
 // DIAGNOSTIC BUILD ONLY (tools/stamps.py): s_memtime stamps at the phase boundaries of the step kernel, one row per
 // wave, to see where a small shard's few microseconds go. Never timed as a whole: the stamps' fences forbid overlaps.
 #ifndef DRONE_STAMPS
@@ -104,8 +84,11 @@
 #define DRONE_STAMP(k) do {} while (0)
 #endif
 
-#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on (3: as 2, and the first chunk's vector loads are issued by hand ahead of the kernel's first scalar-memory wait — raw_issue / raw_land) — 0: wherever the compiler sinks their scalar loads (three dependent scalar-memory round trips ahead of the state loads); 1: all in the kernel's first scalar batch (one round trip); 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count: none). Round 4
+#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count, Makefile PRELOAD); 0: wherever the compiler sinks their scalar loads (the build without kernarg preloading: make PRELOAD= EXTRA=-DDRONE_EARLY_ARGS=0). Round 4; the two forms in between (one scalar batch; the first loads issued by hand) are profiles/r04_ab/early_args_1_3_not_kept.patch
 #define DRONE_EARLY_ARGS 2
+#endif
+#if DRONE_EARLY_ARGS != 0 && DRONE_EARLY_ARGS != 2
+#error "DRONE_EARLY_ARGS is 0 or 2"
 #endif
 
 #ifndef DRONE_SCALAR_RESET  // 1: the register-resident kernels hash the reset draws of ended episodes on the SCALAR unit, one ended lane at a time (lane_reset_wave), instead of in vector instructions for all 64 lanes. Measured (round 4, profiles/r04_ab/ab_sreset_*): -22 VALU instructions per wave-step, but the dependent scalar chain (~60 instructions per ended lane) stalls the wave: fused rollout -0.9 % at 2^20 envs, +2 % at 262 144, +7 % at 131 072; step_many K=32 +6 % at 2^20. Negative result: off
@@ -198,16 +181,14 @@ __device__ __forceinline__ uint64_t whole_lines(uint64_t m, uint32_t enabled) {
 __device__ __forceinline__ bool lane_bit(uint64_t m) { return (m >> (threadIdx.x & (kWave - 1))) & 1ull; }
 
 // ---- plane <-> register marshalling ----
-// one lane's state as it sits in HBM: issued as a block of loads, unpacked when first needed, so that a
-// workgroup can have the NEXT chunk's loads in flight while it computes the current one
+// one lane's state as it sits in HBM: issued as a block of loads, unpacked when first needed
 template <int TASK>
 struct RawLane {
     float4 a, b, c, d, e, t, w, act;
 };
 
-// No branches in here: the wait-count pass merges the outstanding-load state of all paths into a join and would
-// make the consumer of the CURRENT chunk wait for the prefetched one too. `ia` is the action row to read, already
-// clamped into the buffer by the caller (lanes >= n read the last row and never store anything).
+// No branches in here (the wait-count pass merges the outstanding-load state of all paths into a join). `ia` is the action
+// row to read, already clamped into the buffer by the caller (lanes >= n read the last row and never store anything).
 // DT: the derived-target layout (drone_params.hpp): five planes per tile, no target plane to read.
 // MEM: which of the loads carry the non-temporal hint — bit 0 the action rows, bit 1 the state planes. A compile-time choice
 // (a run-time branch here would make the wait-count pass drain all loads at the join), made by the host per handle from the
@@ -238,51 +219,6 @@ __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const fl
     } else {
         R.act = reinterpret_cast<const float4*>(actions)[ia];
     }
-}
-
-// ---- DRONE_EARLY_ARGS == 3: the first chunk's loads issued by hand (round 4) ----
-// A wave's first ~800 cycles at small shards are the round trip of its first scalar loads (the kernarg words beyond the
-// preloaded ones: the 57-word constants block), and the compiler parks an `s_waitcnt lgkmcnt(0)` AHEAD of the state loads
-// even when their addresses come out of preloaded SGPRs: later scalar loads reuse SGPRs of pending ones, and the only way
-// it knows to resolve that hazard is to drain. Issued as inline asm from the kernel's first instructions, the eight vector
-// loads depend on nothing that is pending, so the ~500 cycles of their latency overlap the scalar round trip instead of
-// following it. The compiler does not know these registers are in flight: nothing may touch them between `issue` and
-// `land` (no branch, no use — they are asm outputs consumed only by the asm that waits), and `land` waits for vmcnt(0):
-// these are the oldest vector-memory operations of the wave, so every later wait the compiler computes for its own
-// accesses is at worst early.
-template <int TASK>
-struct RawRegs {
-    f4_t a, b, c, d, e, t, w, act;
-};
-template <bool NT>
-__device__ __forceinline__ void asm_load(f4_t& dst, const void* p) {
-    if (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
-    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
-}
-template <int TASK, int MEM, bool DT>
-__device__ __forceinline__ void raw_issue(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawRegs<TASK>& r) {
-    constexpr bool NT_STATE = (MEM & 2) != 0 || DRONE_NT_STATE_LOADS, NT_ACT = (MEM & 1) != 0 || DRONE_NT_ACTION_LOADS;
-    constexpr uint32_t nph = hot_planes(TASK, DT);
-    asm_load<NT_STATE>(r.a, pl + hot_index(nph, kP0, i, np));
-    asm_load<NT_STATE>(r.b, pl + hot_index(nph, kP1, i, np));
-    asm_load<NT_STATE>(r.c, pl + hot_index(nph, kP2, i, np));
-    asm_load<NT_STATE>(r.d, pl + hot_index(nph, kP3, i, np));
-    asm_load<NT_STATE>(r.e, pl + hot_index(nph, kP4, i, np));
-    if (!DT) asm_load<NT_STATE>(r.t, pl + hot_index(nph, kPT, i, np));
-    if (has_aux_plane<TASK>()) asm_load<NT_STATE>(r.w, pl + hot_index(nph, kPW, i, np));
-    asm_load<NT_ACT>(r.act, reinterpret_cast<const float4*>(actions) + ia);
-}
-template <int TASK, bool DT>
-__device__ __forceinline__ void raw_land(RawRegs<TASK>& r, RawLane<TASK>& R) {
-    if (!DT && has_aux_plane<TASK>()) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.t), "+v"(r.w), "+v"(r.act));
-    else if (!DT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.t), "+v"(r.act));
-    else if (has_aux_plane<TASK>()) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.w), "+v"(r.act));
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d), "+v"(r.e), "+v"(r.act));
-    auto f4 = [](const f4_t& x) { return make_float4(x.x, x.y, x.z, x.w); };
-    R.a = f4(r.a); R.b = f4(r.b); R.c = f4(r.c); R.d = f4(r.d); R.e = f4(r.e);
-    if (!DT) R.t = f4(r.t);
-    if (has_aux_plane<TASK>()) R.w = f4(r.w);
-    R.act = f4(r.act);
 }
 
 // the words of P4 and PT that are not floats: (tick, score_count, episode) and the target, for either layout
@@ -355,7 +291,7 @@ __device__ __forceinline__ void store_lane(float4* __restrict__ pl, uint32_t np,
         state_store(&pl[hot_index(nph, kP4, i, np)], make_float4(L.s.r[3], L.ep_return, u2f(L.tick | (L.score_count << 16)), u2f(L.episode)));
     } else {
         state_store(&pl[hot_index(nph, kP4, i, np)], make_float4(L.s.r[3], L.ep_return, u2f(L.tick), u2f(L.score_count)));
-        if (target_changed && !DRONE_EXP_NO_PT) pl[hot_index(nph, kPT, i, np)] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
+        if (target_changed) pl[hot_index(nph, kPT, i, np)] = make_float4(L.tgt[0], L.tgt[1], L.tgt[2], u2f(L.episode));
     }
     // wind changes every step; a gate normal only together with its centre
     if (TASK == DRONE_TASK_WAYPOINT || (TASK == DRONE_TASK_RACE && target_changed)) pl[hot_index(nph, kPW, i, np)] = make_float4(L.wind[0], L.wind[1], L.wind[2], 0.0f);
@@ -658,64 +594,28 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uin
 
 template <int TASK, bool COMPACT, int MEM, bool DT>
 __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
-#define DRONE_ASM_FIRST_LOADS (DRONE_EARLY_ARGS == 3 && DRONE_STEP_TILES == 1 && !DRONE_STAMPS)
-#if DRONE_ASM_FIRST_LOADS
-    // the first (only) chunk's loads, from preloaded SGPRs and the thread id alone, ahead of everything. The sweep direction
-    // uses the step counter of the launch arguments: in graph-safe mode (device counters) that one is stale, which changes
-    // which workgroup takes which chunk — any bijection is correct — and nothing else.
-    RawRegs<TASK> early;
-    {
-        // my_chunk without control flow (selects): the loads must sit in the kernel's entry block, ahead of every wait
-        const uint32_t xcd = blockIdx.x & 7u, q = pre_nwg >> 3, r = pre_nwg & 7u;
-        const uint32_t c1 = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
-        uint32_t c = (pre_order & 1u) ? c1 : blockIdx.x;
-        c = ((pre_order & 2u) && (pre_gstep & 1u)) ? pre_nwg - 1u - c : c;
-        const uint32_t bb = c * (uint32_t)kBlock;
-        raw_issue<TASK, MEM, DT>(pre_planes, pre_act, pre_n_pad, bb + threadIdx.x, min(bb + threadIdx.x, pre_n - 1u), early);
-        __builtin_amdgcn_sched_barrier(0);  // nothing that follows (scalar loads of the rest of the arguments, their waits) may be scheduled above the loads
-    }
-#endif
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
-#if DRONE_EARLY_ARGS >= 2
+#if DRONE_EARLY_ARGS == 2
     a.v.planes = const_cast<float4*>(pre_planes); a.v.act = pre_act; a.v.ctr = const_cast<uint32_t*>(pre_ctr);
     a.v.n = pre_n; a.v.n_pad = pre_n_pad; a.v.order = pre_order; a.nwg = pre_nwg; a.gstep = pre_gstep; a.done_slot = pre_slot;
-#elif DRONE_EARLY_ARGS == 1
-    // A wave's first microsecond at small shards is its prologue: the state loads cannot go out before the scalar loads
-    // of the words their addresses depend on have come back, and the compiler sank some of those (the plane pointers, the
-    // hidden-argument grid size) behind branches — three dependent scalar-memory round trips. Naming them all here makes
-    // them part of the one batch the kernel opens with (the empty asm needs them in SGPRs at this point).
-    {
-        const float4* p0 = a.v.planes;
-        const float* p1 = a.v.act;
-        const uint32_t* p2 = a.v.ctr;
-        uint32_t w0 = a.v.n, w1 = a.v.n_pad, w2 = a.v.order, w3 = a.nwg, w4 = a.gstep, w5 = a.done_slot, w6 = a.v.stride;
-        asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(w0), "s"(w1), "s"(w2), "s"(w3), "s"(w4), "s"(w5), "s"(w6));
-    }
 #endif
     const uint32_t n = a.v.n, np = a.v.stride, n_pad = a.v.n_pad;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float4* const tile = sh.obs_tile[threadIdx.x / kWave];
-    // This workgroup walks DRONE_STEP_TILES consecutive 256-drone chunks. Lanes [n, n_pad) exist in the planes
-    // and hold a valid reset state: they load and compute like the rest and store nothing.
+    // One 256-drone chunk per workgroup (two or more, software-pipelined, measured +13 %: profiles/r02_ab/step_tiles_not_kept.patch).
+    // Lanes [n, n_pad) exist in the planes and hold a valid reset state: they load and compute like the rest and store nothing
+    // into the caller's buffers.
     const Counters ctr = read_counters(a);
     const uint32_t gstep = ctr.gstep, done_slot = ctr.launches & 1u;
-#if DRONE_ASM_FIRST_LOADS
-    uint32_t block_base = my_chunk(a.v.order, a.gstep, a.nwg) * (uint32_t)kBlock;  // the chunk whose loads are in flight (launch-argument step counter, see above)
-#else
-    uint32_t block_base = my_chunk(a.v.order, gstep, a.nwg) * (uint32_t)(DRONE_STEP_TILES * kBlock);
-#endif
+    const uint32_t block_base = my_chunk(a.v.order, gstep, a.nwg) * (uint32_t)kBlock;
 #if DRONE_STAMPS
     unsigned long long stamp_[kStampSlots];
     stamp_[8] = __builtin_amdgcn_s_memrealtime();
 #endif
     DRONE_STAMP(0);  // entry
     RawLane<TASK> cur;
-#if DRONE_ASM_FIRST_LOADS
-    raw_land<TASK, DT>(early, cur);
-#else
     load_raw<TASK, MEM, DT>(a.v.planes, a.v.act, a.v.n_pad, block_base + threadIdx.x, min(block_base + threadIdx.x, n - 1u), cur);
-#endif
 #if DRONE_EARLY_ARGS == 2
     // everything above came out of preloaded SGPRs: the state loads are in flight before the kernel's first scalar-memory
     // wait. Nothing may be scheduled across this point (a hoisted s_load + s_waitcnt, or a load sunk below one).
@@ -723,106 +623,79 @@ __global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_
 #endif
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
     peer_ack(a);
-#pragma unroll
-    for (int t = 0; t < DRONE_STEP_TILES; t++, block_base += kBlock) {
-        const uint32_t i = block_base + threadIdx.x;
-        const bool valid = i < n;
-        RawLane<TASK> nxt;
-        const bool more = t + 1 < DRONE_STEP_TILES && block_base + kBlock < n_pad;  // workgroup-uniform
-        if (t + 1 < DRONE_STEP_TILES) {  // compile-time: the next chunk's loads are in flight while this one computes
-            const uint32_t j = min(i + kBlock, n_pad - kBlock + threadIdx.x);  // past the end: this chunk again (unused)
-            load_raw<TASK, MEM, DT>(a.v.planes, a.v.act, a.v.n_pad, j, min(j, n - 1u), nxt);
-        }
+    const uint32_t i = block_base + threadIdx.x;
+    const bool valid = i < n;
 
-        Lane L;
-        float act[4];
-        DRONE_STAMP(1);  // loads issued
-        unpack_lane<TASK, DT>(P, cur, P.env_offset + i, L, act);
+    Lane L;
+    float act[4];
+    DRONE_STAMP(1);  // loads issued
+    unpack_lane<TASK, DT>(P, cur, P.env_offset + i, L, act);
 #if DRONE_STAMPS
-        asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.r[3]), "v"(L.tgt[0]), "v"(act[0]));  // everything has landed
+    asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.r[3]), "v"(L.tgt[0]), "v"(act[0]));  // everything has landed
 #endif
-        DRONE_STAMP(2);  // data arrived
-        StepOut out;
-        step_any<TASK>(P, L, tile, act, P.env_offset + i, gstep, out);
+    DRONE_STAMP(2);  // data arrived
+    StepOut out;
+    step_any<TASK>(P, L, tile, act, P.env_offset + i, gstep, out);
 #if DRONE_STAMPS
-        asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.q[0]), "v"(out.reward));
+    asm volatile("" ::"v"(L.s.p[0]), "v"(L.s.q[0]), "v"(out.reward));
 #endif
-        DRONE_STAMP(3);  // integrated, reward, reset
-        const bool done = valid && (out.oob || out.trunc);
+    DRONE_STAMP(3);  // integrated, reward, reset
+    const bool done = valid && (out.oob || out.trunc);
 
-        // Episode ends (~1 % of the lanes, but some lane in about half of the waves): the per-env log sums are a
-        // read-modify-write of two cold planes. Their loads go out FIRST, ahead of this lane's stores, and are
-        // consumed at the very end of the chunk: vmcnt retires in issue order, so a load issued behind the
-        // state stores could only be waited for together with the write acknowledgements of those (non-temporal,
-        // HBM-latency) stores — which stalled the wave, and through the barrier its whole workgroup (−10 % at 2^22 envs).
-        // No branch around the stores either (a join would merge the outstanding-access counts of both paths and
-        // force a full drain): the padding lanes [n, n_pad) own their plane slots and simply evolve like phantom
-        // envs; only the caller's buffers are exactly n long, and there the padding lanes' reward goes to a sink.
-        const bool ended = !DRONE_EXP_NO_LOG && (out.oob || out.trunc);  // padding lanes included: their log slots exist too
-        const bool log_lane = lane_bit(whole_lines(__ballot(ended), a.v.line_complete));   // this lane's log slots share a line with an ended episode's
-        const bool tgt_lane = !DT && lane_bit(whole_lines(__ballot(out.target_changed), a.v.line_complete));
-        float4 l0, l1;
-        if (log_lane) {
-            l0 = a.v.cold[i];
-            l1 = a.v.cold[np + i];
-        }
-        store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, tgt_lane, DT);
-        out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], out.reward);
-        DRONE_STAMP(4);  // state stores issued
+    // Episode ends (~1 % of the lanes, but some lane in about half of the waves): the per-env log sums are a
+    // read-modify-write of two cold planes. Their loads go out FIRST, ahead of this lane's stores, and are
+    // consumed at the very end of the chunk: vmcnt retires in issue order, so a load issued behind the
+    // state stores could only be waited for together with the write acknowledgements of those (non-temporal,
+    // HBM-latency) stores — which stalled the wave, and through the barrier its whole workgroup (−10 % at 2^22 envs).
+    // No branch around the stores either (a join would merge the outstanding-access counts of both paths and
+    // force a full drain): the padding lanes [n, n_pad) own their plane slots and simply evolve like phantom
+    // envs; only the caller's buffers are exactly n long, and there the padding lanes' reward goes to a sink.
+    const bool ended = out.oob || out.trunc;  // padding lanes included: their log slots exist too
+    const bool log_lane = lane_bit(whole_lines(__ballot(ended), a.v.line_complete));   // this lane's log slots share a line with an ended episode's
+    const bool tgt_lane = !DT && lane_bit(whole_lines(__ballot(out.target_changed), a.v.line_complete));
+    float4 l0, l1;
+    if (log_lane) {
+        l0 = a.v.cold[i];
+        l1 = a.v.cold[np + i];
+    }
+    store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, tgt_lane, DT);
+    out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], out.reward);
+    DRONE_STAMP(4);  // state stores issued
 
-        if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
-            const uint64_t m_done = __ballot(done);
-            if (m_done != 0) {  // wave-uniform
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.v.done_count + done_slot, (uint32_t)__popcll(m_done));
-                base = __shfl(base, 0);
-                if (done) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
-                    a.v.done_ids[base + rank] = i;
-                }
+    if (COMPACT) {  // done-id list: ballot -> one atomic per wave -> mbcnt rank
+        const uint64_t m_done = __ballot(done);
+        if (m_done != 0) {  // wave-uniform
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.v.done_count + done_slot, (uint32_t)__popcll(m_done));
+            base = __shfl(base, 0);
+            if (done) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_done, 0u));
+                a.v.done_ids[base + rank] = i;
             }
         }
-
-#if !DRONE_LOG_FOLD_LATE
-        if (log_lane) {
-            if (ended) fold_log(l0, l1, out);
-            a.v.cold[i] = l0;
-            a.v.cold[np + i] = l1;
-        }
-#endif
-        float o[DRONE_OBS_DIM_MAX];
-        obs_any<TASK>(P, L, tile, o);
-        DRONE_STAMP(5);  // observation math done
-#if DRONE_STEP_WAVE_OUTPUTS
-        if (block_base + kBlock <= n) {  // workgroup-uniform
-            const uint32_t wave_base = i - lane;
-            write_outputs_wave<obs_vec<TASK>()>(tile, a.v.obs + (size_t)wave_base * (4 * obs_vec<TASK>()), a.v.term + wave_base, a.v.trunc + wave_base,
-                                                (a.flags_aligned & 3u) == 3u, o, out.oob, out.trunc);
-        } else
-#endif
-        write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base, (uint32_t)t & 1u);
-        DRONE_STAMP(6);  // LDS transpose, barrier, observation / flag stores issued
-#if DRONE_LOG_FOLD_LATE
-        if (log_lane) {  // last of all: the two loads have been in flight since before the state stores
-            asm volatile("" : "+v"(l0.x), "+v"(l1.x));  // pins the fold down here (the optimiser would hoist it up to the loads and wait there)
-            if (ended) fold_log(l0, l1, out);
-            a.v.cold[i] = l0;
-            a.v.cold[np + i] = l1;
-        }
-#endif
-#if DRONE_STAMPS
-        DRONE_STAMP(7);  // log fold done
-        stamp_[9] = __builtin_amdgcn_s_memrealtime();
-        if (a.v.stamps && lane == 0) {
-            unsigned long long* row = a.v.stamps + (size_t)(i / kWave) * kStampSlots;
-            for (int k = 0; k < kStampSlots; k++) row[k] = stamp_[k];
-        }
-#endif
-        if (!more) break;
-        cur = nxt;
     }
+
+    float o[DRONE_OBS_DIM_MAX];
+    obs_any<TASK>(P, L, tile, o);
+    DRONE_STAMP(5);  // observation math done
+    write_outputs<obs_vec<TASK>()>(sh, a.v, a.flags_aligned, o, out.oob, out.trunc, i, block_base);
+    DRONE_STAMP(6);  // LDS transpose, barrier, observation / flag stores issued
+    if (log_lane) {  // last of all: the two loads have been in flight since before the state stores
+        asm volatile("" : "+v"(l0.x), "+v"(l1.x));  // pins the fold down here (the optimiser would hoist it up to the loads and wait there)
+        if (ended) fold_log(l0, l1, out);
+        a.v.cold[i] = l0;
+        a.v.cold[np + i] = l1;
+    }
+#if DRONE_STAMPS
+    DRONE_STAMP(7);  // log fold done
+    stamp_[9] = __builtin_amdgcn_s_memrealtime();
+    if (a.v.stamps && lane == 0) {
+        unsigned long long* row = a.v.stamps + (size_t)(i / kWave) * kStampSlots;
+        for (int k = 0; k < kStampSlots; k++) row[k] = stamp_[k];
+    }
+#endif
     advance_counters(a, ctr, 1u, 1u);
-    peer_post(a, block_base / (uint32_t)kBlock);  // (the loop above leaves by its break: block_base is still the chunk just written; per-chunk words assume DRONE_STEP_TILES == 1)
+    peer_post(a, block_base / (uint32_t)kBlock);
 }
 
 // =====================================================================
@@ -1262,7 +1135,7 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     StepArgs a = make_args(v, gstep);
     if (sig) a.sig = *sig;
     a.done_slot = done_slot & 1u;
-    const dim3 g((grid_for(v.n) + DRONE_STEP_TILES - 1) / DRONE_STEP_TILES), b(kBlock);
+    const dim3 g(grid_for(v.n)), b(kBlock);
     a.nwg = g.x;
     const bool compact = v.done_ids != nullptr;
     const int mem = (int)((v.order >> 2) & 3u);  // bit 0: non-temporal action loads, bit 1: non-temporal state loads (DeviceView::order bits 2, 3)
