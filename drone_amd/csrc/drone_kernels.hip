@@ -22,8 +22,8 @@
 // The sweep order over the envs, the line widening and the action-load hint are
 // launch arguments chosen by the host from the step's footprint (DeviceView).
 // The 57-word constants block (KParams) reaches the lanes through the kernarg
-// segment (scalar loads -> SGPR operands; default), staged through LDS by each
-// workgroup (DRONE_PARAMS_IN_LDS=1) or by scalar loads from HBM (DRONE_PARAMS_GLOBAL=1).
+// segment (scalar loads -> SGPR operands; default) or staged through LDS by each
+// workgroup (DRONE_PARAMS_IN_LDS=1).
 //
 // The path is elementwise: no MFMA. Roofline = HBM for the per-step kernel,
 // f32 VALU for the fused rollout.
@@ -36,35 +36,15 @@
 #include "drone_kernels.h"
 #include "drone_lane.hpp"
 
-// ---- tuning knobs (compile-time). Defaults are the measured best at equal
-// memory placement (tools/ab_step.py): DESIGN.md, profiles/r01_ab/, profiles/r02_ab/ ----
-#ifndef DRONE_PARAMS_GLOBAL  // 1: KParams read by scalar loads from the handle's HBM copy (constant address space) instead of by value in the kernarg segment: a 228-B shorter kernarg fetch ahead of the first state load (no measurable effect, ab_pg_*)
-#define DRONE_PARAMS_GLOBAL 0
-#endif
-#ifndef DRONE_PARAMS_IN_LDS  // 1: stage KParams HBM -> LDS per workgroup; 0: kernarg scalar loads (-2.4 % step, -13 % rollout)
+// ---- compile-time variants. What used to be knobs here and lost its measurement now lives as a patch beside its log
+// (profiles/r06_pruned/README.md: one patch that puts them all back, each with its log): plain instead of non-temporal output / state stores (+21 % / +4 %), non-temporal state
+// loads everywhere, several chunks per workgroup, per-wave outputs in the step kernel, wave-count caps, constants by scalar
+// loads from HBM, the hand-issued first loads, scalar-unit reset hashing, priority rotation, the RK4's constants in vector
+// registers. ----
+#ifndef DRONE_PARAMS_IN_LDS  // 1: stage KParams HBM -> LDS per workgroup (the north-star's wording; tests/test_parity_gpu.py builds and checks it); 0: kernarg scalar loads (-2.4 % step, -13 % rollout)
 #define DRONE_PARAMS_IN_LDS 0
 #endif
-#ifndef DRONE_NT_STORES  // 1: non-temporal stores for observations / rewards / flags (plain stores: +21 % at 2^20 envs, +11 % at 131 072, 0 at 2^22; ab_nt_*)
-#define DRONE_NT_STORES 1
-#endif
-#ifndef DRONE_NT_STATE_STORES  // 1: non-temporal stores for the state planes too (plain: +0.4 % at 2^20, +4 % at 131 072, 0 at 2^22)
-#define DRONE_NT_STATE_STORES 1
-#endif
-#ifndef DRONE_NT_STATE_LOADS  // 1: non-temporal loads of the state planes in the per-step kernel (experiment, round 4: do the planes stay in the Infinity Cache if only their STORES allocate?)
-#define DRONE_NT_STATE_LOADS 0
-#endif
-#ifndef DRONE_NT_ACTION_LOADS  // 1: force non-temporal action loads at every size (default: only the instantiation the host picks for HBM-only footprints)
-#define DRONE_NT_ACTION_LOADS 0
-#endif
-#ifndef DRONE_XCD_REMAP  // 0: compile the per-XCD chunk map out (it is otherwise a launch-time choice: DeviceView::order bit 0)
-#define DRONE_XCD_REMAP 1
-#endif
-#ifndef DRONE_STEP_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the per-step kernel; 0 = unset. 5 keeps the race task at 93 VGPRs (97 unbounded), no scratch
-#define DRONE_STEP_MIN_WAVES 5
-#endif
-#ifndef DRONE_STEP_MAX_WAVES  // >0: cap waves per SIMD of the per-step kernel (amdgpu_waves_per_eu)
-#define DRONE_STEP_MAX_WAVES 0
-#endif
+constexpr int kStepMinWaves = 5;  // __launch_bounds__ 2nd argument of the per-step kernel: keeps the race task at 93 VGPRs (97 unbounded), no scratch
 
 // DIAGNOSTIC BUILD ONLY (tools/stamps.py): s_memtime stamps at the phase boundaries of the step kernel, one row per
 // wave, to see where a small shard's few microseconds go. Never timed as a whole: the stamps' fences forbid overlaps.
@@ -84,33 +64,11 @@
 #define DRONE_STAMP(k) do {} while (0)
 #endif
 
-#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count, Makefile PRELOAD); 0: wherever the compiler sinks their scalar loads (the build without kernarg preloading: make PRELOAD= EXTRA=-DDRONE_EARLY_ARGS=0). Round 4; the two forms in between (one scalar batch; the first loads issued by hand) are profiles/r04_ab/early_args_1_3_not_kept.patch
+#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count, Makefile PRELOAD); 0: wherever the compiler sinks their scalar loads (the build without kernarg preloading: make PRELOAD= EXTRA=-DDRONE_EARLY_ARGS=0). Round 4; the two forms in between (one scalar batch; the first loads issued by hand) are profiles/r06_pruned/
 #define DRONE_EARLY_ARGS 2
 #endif
 #if DRONE_EARLY_ARGS != 0 && DRONE_EARLY_ARGS != 2
 #error "DRONE_EARLY_ARGS is 0 or 2"
-#endif
-
-#ifndef DRONE_SCALAR_RESET  // 1: the register-resident kernels hash the reset draws of ended episodes on the SCALAR unit, one ended lane at a time (lane_reset_wave), instead of in vector instructions for all 64 lanes. Measured (round 4, profiles/r04_ab/ab_sreset_*): -22 VALU instructions per wave-step, but the dependent scalar chain (~60 instructions per ended lane) stalls the wave: fused rollout -0.9 % at 2^20 envs, +2 % at 262 144, +7 % at 131 072; step_many K=32 +6 % at 2^20. Negative result: off
-#define DRONE_SCALAR_RESET 0
-#endif
-#ifndef DRONE_CARRY_ROTOR  // 1: the register-resident kernels carry the rotor inputs from step to step (Lane::u); 0: recompute them every step (A/B only)
-#define DRONE_CARRY_ROTOR 1
-#endif
-#ifndef DRONE_PRIO_ROTATE  // 1: the register-resident kernels rotate s_setprio among the waves that share a SIMD (PrioRotor below); 0 (default): the hardware's oldest-first arbitration. Measured (round 5, profiles/r05_ab/ab_prio_rollout_*.txt): the rotation does level the waves of a SIMD (they end 132 / 148 us after the start at 131 072 envs instead of 110 / 152) but the SIMD retires less while priorities differ (one VALU per 3.3 cycles against 2.83): -2 % at 131 072 envs, +1 % at 262 144, 0 at 2^20, and a period of 32 steps swings from -5 % to +9 % between sizes. Negative result: off
-#define DRONE_PRIO_ROTATE 0
-#endif
-#ifndef DRONE_PRIO_ROTATE_MANY  // the same in the K-steps-per-launch kernel. Off: that kernel has no scalar register to spare (the one word of state costs the swarm / waypoint instantiations 100-180 v_readlane / v_writelane spills)
-#define DRONE_PRIO_ROTATE_MANY 0
-#endif
-#ifndef DRONE_PRIO_PERIOD_LOG2  // the priorities move on every 2^k env steps
-#define DRONE_PRIO_PERIOD_LOG2 3
-#endif
-#ifndef DRONE_ROLLOUT_MIN_WAVES  // __launch_bounds__ 2nd argument of the fused rollout kernel; 0 = unset
-#define DRONE_ROLLOUT_MIN_WAVES 0
-#endif
-#ifndef DRONE_ROLLOUT_MAX_WAVES  // >0: cap waves per SIMD of the fused rollout kernel
-#define DRONE_ROLLOUT_MAX_WAVES 0
 #endif
 
 namespace drone {
@@ -131,37 +89,18 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 
-// stores of data this path never reads back
-__device__ __forceinline__ void out_store(float* p, float v) {
-#if DRONE_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+// stores of data this path never reads back: non-temporal (plain stores: +21 % at 2^20 envs, +11 % at 131 072, 0 at 2^22; profiles/r01_ab/ab_nt_*)
+__device__ __forceinline__ void out_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void out_store(float4* p, const float4& v) {
-#if DRONE_NT_STORES
     const f4_t x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
-#else
-    *p = v;
-#endif
 }
-__device__ __forceinline__ void out_store(u4_t* p, const u4_t& v) {
-#if DRONE_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
+__device__ __forceinline__ void out_store(u4_t* p, const u4_t& v) { __builtin_nontemporal_store(v, p); }
 
+// the state planes too: the next step's loads come from HBM or the Infinity Cache either way (plain: +0.4 % at 2^20 envs, +4 % at 131 072)
 __device__ __forceinline__ void state_store(float4* p, const float4& v) {
-#if DRONE_NT_STATE_STORES
     const f4_t x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<f4_t*>(p));
-#else
-    *p = v;
-#endif
 }
 
 // A scattered 16-byte store into HBM is a partial-line write: the memory controller turns it into a read-modify-write
@@ -197,7 +136,7 @@ struct RawLane {
 // action rows: +19 % at 2^20, -2 % at 2^23 — profiles/r04_ab/band_*.txt, r02_ab/ab_o6_*.txt).
 template <int TASK, int MEM, bool DT>
 __device__ __forceinline__ void load_raw(const float4* __restrict__ pl, const float* __restrict__ actions, uint32_t np, uint32_t i, uint32_t ia, RawLane<TASK>& R) {
-    constexpr bool NT_STATE = (MEM & 2) != 0 || DRONE_NT_STATE_LOADS, NT_ACT = (MEM & 1) != 0 || DRONE_NT_ACTION_LOADS;
+    constexpr bool NT_STATE = (MEM & 2) != 0, NT_ACT = (MEM & 1) != 0;
     auto plane = [&](int p) {
         const uint32_t e = hot_index(hot_planes(TASK, DT), p, i, np);
         if (NT_STATE) {
@@ -310,7 +249,7 @@ struct StepArgs {
     uint32_t done_slot;      // which of the two done-list counters this step launch adds to (the host alternates per STEP launch)
     uint32_t nwg;            // workgroups of this launch (= gridDim.x, which the kernel would otherwise fetch from the hidden arguments in a scalar round trip of its own)
     LaunchSig sig;           // what this launch publishes itself (drone_kernels.h): peer-store handshake flags, per-chunk completion words; all null otherwise
-#if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
+#if !DRONE_PARAMS_IN_LDS
     KParams kp;              // constants by value: scalar loads from the kernarg segment
 #endif
 };
@@ -331,9 +270,6 @@ __device__ __forceinline__ const KParams& stage_params(KParams& sp, const uint32
     __syncthreads();
     return sp;
 }
-#elif DRONE_PARAMS_GLOBAL
-typedef const KParams __attribute__((address_space(4))) ConstKParams;  // constant address space: uniform loads become s_load
-#define DRONE_PARAMS(sh, a) (*(const KParams*)(ConstKParams*)(a).v.kp)
 #else
 #define DRONE_PARAMS(sh, a) ((a).kp)
 #endif
@@ -471,17 +407,16 @@ __device__ __forceinline__ void swarm_neighbour(const KParams& P, const Lane& L,
 // CARRY: the state stays in registers from step to step and carries the rotor inputs (Lane::u) with it.
 // PK: the RK4 substep in packed f32 instructions (small shards; drone_pk.hpp).
 // INRANGE: `act` was drawn by random_action in this kernel (values in [-1, 1): the clamp of SPEC.md section 5 step 1 is the identity).
-// SRESET: ended episodes' reset draws hashed on the scalar unit (lane_reset_wave): only where the whole wave is in the call.
-template <int TASK, bool CARRY = false, bool PK = false, bool INRANGE = false, bool SRESET = false>
+template <int TASK, bool CARRY = false, bool PK = false, bool INRANGE = false>
 __device__ __forceinline__ void step_any(const KParams& P, Lane& L, float4* tile, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     if (TASK == DRONE_TASK_SWARM) {
         StepCtx ctx;
         lane_integrate<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, ctx);
         float nn_d2, nn_e[3];
         swarm_neighbour(P, L, tile, nn_d2, nn_e);
-        lane_finish<TASK, CARRY, SRESET>(P, L, env, ctx, nn_d2, out);
+        lane_finish<TASK, CARRY>(P, L, env, ctx, nn_d2, out);
     } else {
-        lane_step<TASK, CARRY, PK, INRANGE, SRESET>(P, L, act, env, gstep, out);
+        lane_step<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, out);
     }
 }
 
@@ -561,26 +496,13 @@ __device__ __forceinline__ void peer_post(const StepArgs& a, uint32_t chunk) {
 // Bijective for any grid size; a speed choice only (profiles/r02_ab/ab_zz_*.txt, ab_order_*.txt).
 __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uint32_t nwg) {
     uint32_t c = blockIdx.x;
-#if DRONE_XCD_REMAP
     if (order & 1u) {
         const uint32_t xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
         c = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-#endif
     if ((order & 2u) && (gstep & 1u)) c = nwg - 1u - c;
     return c;
 }
-
-#if DRONE_STEP_MIN_WAVES > 0
-#define DRONE_STEP_BOUNDS __launch_bounds__(kBlock, DRONE_STEP_MIN_WAVES)
-#else
-#define DRONE_STEP_BOUNDS __launch_bounds__(kBlock)
-#endif
-#if DRONE_STEP_MAX_WAVES > 0
-#define DRONE_STEP_WAVES __attribute__((amdgpu_waves_per_eu(1, DRONE_STEP_MAX_WAVES)))
-#else
-#define DRONE_STEP_WAVES
-#endif
 
 // =====================================================================
 // per-step kernel (SPEC.md §5): configs 1–4
@@ -593,17 +515,17 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uin
                               uint32_t pre_order, uint32_t pre_nwg, uint32_t pre_gstep, uint32_t pre_slot
 
 template <int TASK, bool COMPACT, int MEM, bool DT>
-__global__ DRONE_STEP_BOUNDS DRONE_STEP_WAVES void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
+__global__ __launch_bounds__(kBlock, kStepMinWaves) void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
 #if DRONE_EARLY_ARGS == 2
     a.v.planes = const_cast<float4*>(pre_planes); a.v.act = pre_act; a.v.ctr = const_cast<uint32_t*>(pre_ctr);
     a.v.n = pre_n; a.v.n_pad = pre_n_pad; a.v.order = pre_order; a.nwg = pre_nwg; a.gstep = pre_gstep; a.done_slot = pre_slot;
 #endif
-    const uint32_t n = a.v.n, np = a.v.stride, n_pad = a.v.n_pad;
+    const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float4* const tile = sh.obs_tile[threadIdx.x / kWave];
-    // One 256-drone chunk per workgroup (two or more, software-pipelined, measured +13 %: profiles/r02_ab/step_tiles_not_kept.patch).
+    // One 256-drone chunk per workgroup (two or more, software-pipelined, measured +13 %: profiles/r06_pruned/).
     // Lanes [n, n_pad) exist in the planes and hold a valid reset state: they load and compute like the rest and store nothing
     // into the caller's buffers.
     const Counters ctr = read_counters(a);
@@ -723,68 +645,13 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     peer_post(a, blockIdx.x);
 }
 
-// Fair shares of a SIMD for the register-resident kernels (round 5). VALU issue is arbitrated among the waves
-// of a SIMD by priority, then AGE: with every wave at priority 0 the oldest runs as if alone (1852 cycles per env step of the
-// hover rollout), the second gets what is left (3186), a third and fourth almost nothing (tools/wg_census.py: the four waves of
-// a SIMD at 262 144 envs end after 106, 150, 210 and 266 us). The SIMD's total rate is the same either way while all of them
-// are resident — but they leave one by one, and the last wave of a SIMD runs ALONE, at the single-wave issue rate (one VALU
-// per 4.5 cycles against 2.5-2.8 for the SIMD with company), for the last 20-45 % of the launch. Rotating the priorities —
-// every 2^DRONE_PRIO_PERIOD_LOG2 env steps the waves move on one place in a cycle of `mod` priority levels, each starting from
-// its hardware wave slot (HW_ID[3:0]: distinct among the waves resident on one SIMD) — keeps them level, so they finish
-// together and the SIMD is shared to the end. `mod` = waves resident per SIMD for this launch (2 ... 4; the host knows the
-// grid and the kernel's register budget), 0 / 1 = off (a lone wave per SIMD has nobody to share with). Scalar unit only; the
-// priority is a speed hint, never a result.
-struct PrioRotor {
-    uint32_t x;  // ONE scalar register (the register-resident kernels have none to spare): bits 1:0 this wave's priority now, bits 3:2 levels - 1 (0 = off)
-    __device__ __forceinline__ void set() const {
-        switch (x & 3u) {  // s_setprio takes an immediate
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-    }
-    __device__ __forceinline__ void init(uint32_t m) {
-        const uint32_t mod = (DRONE_PRIO_ROTATE && m >= 2u) ? (m > 4u ? 4u : m) : 0u;
-        x = 0u;
-        if (mod) {
-            uint32_t slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_REG_HW_ID bits 3:0: this wave's slot on its SIMD
-            while (slot >= mod) slot -= mod;
-            x = ((mod - 1u) << 2) | slot;
-            set();
-        }
-    }
-    // before env step t of the launch; the priorities move on when (t & mask) == 0
-    __device__ __forceinline__ void tick(uint32_t t, uint32_t mask) {
-        if ((x >> 2) && t != 0u && (t & mask) == 0u) {
-            const uint32_t p = (x & 3u) + 1u;
-            x = (x & 12u) | (p > (x >> 2) ? 0u : p);
-            set();
-        }
-    }
-    __device__ __forceinline__ void done() const {
-        if (x >> 2) __builtin_amdgcn_s_setprio(0);
-    }
-};
-
 // =====================================================================
 // fused rollout (SPEC.md §9): config 5. State stays in registers for the
 // whole horizon; actions come from the counter RNG; HBM is touched once on
 // the way in and once on the way out.
 // =====================================================================
-#if DRONE_ROLLOUT_MIN_WAVES > 0
-#define DRONE_ROLLOUT_BOUNDS __launch_bounds__(kBlock, DRONE_ROLLOUT_MIN_WAVES)
-#else
-#define DRONE_ROLLOUT_BOUNDS __launch_bounds__(kBlock)
-#endif
-#if DRONE_ROLLOUT_MAX_WAVES > 0
-#define DRONE_ROLLOUT_WAVES __attribute__((amdgpu_waves_per_eu(1, DRONE_ROLLOUT_MAX_WAVES)))
-#else
-#define DRONE_ROLLOUT_WAVES
-#endif
-
 template <int TASK, bool PK>
-__global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(StepArgs a, uint32_t horizon, uint32_t prio_mod) {
+__global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
@@ -796,7 +663,7 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
     Lane L;
     const bool dt = a.v.derived_target != 0;
     load_lane<TASK>(P, a.v.planes, a.v.n_pad, i, dt, L);
-    L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>)
+    L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>: -18 operations per substep, bit-identical)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
     peer_ack(a);
@@ -805,23 +672,18 @@ __global__ DRONE_ROLLOUT_BOUNDS DRONE_ROLLOUT_WAVES void drone_rollout_kernel(St
 #if DRONE_STAMPS  // diagnostic build: the shader clock this kernel holds = delta s_memtime / delta s_memrealtime x 100 MHz (tools/rollout_clock.py)
     const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    PrioRotor prio;
-    prio.init(prio_mod);
-    KParams Pv = P;  // the step loop's view of the constants (with -DDRONE_RK4_VGPR_CONSTS=1: the RK4's sixteen in vector registers — drone_lane.hpp; measured a wash, off)
-    if (!PK) rk4_consts_to_vgprs(Pv);
+    const KParams Pv = P;  // the step loop's own copy of the constants (left from the round-5 vector-register trial: dropping it moves 8-10 instructions of every instantiation; kept so that the measured ISA ships, tests/test_isa_frozen.py)
     for (uint32_t t = 0; t < horizon; t++) {
-        prio.tick(t, (1u << DRONE_PRIO_PERIOD_LOG2) - 1u);
         float act[4];
         random_action(P.key_action, env, gstep0 + t, act);
         StepOut out;
-        step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, true, (DRONE_SCALAR_RESET != 0) && !PK>(Pv, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
+        step_any<TASK, true, PK, true>(Pv, L, sh.obs_tile[threadIdx.x / kWave], act, env, gstep0 + t, out);
         rsum = rsum + out.reward;
         any_term |= out.oob;
         any_trunc |= out.trunc;
         any_target |= out.target_changed;
         if (out.oob || out.trunc) fold_log(l0, l1, out);
     }
-    prio.done();
 #if DRONE_STAMPS
     asm volatile("" ::"v"(rsum), "v"(L.s.p[0]));
     if (a.v.stamps && (threadIdx.x & (kWave - 1)) == 0) {
@@ -876,7 +738,6 @@ struct ManyArgs {
     uint32_t* done_ids;    // [K][n] (compact_done) or null
     uint32_t* done_count;  // [K], zeroed by the host before the launch
     uint32_t k_steps;
-    uint32_t prio_mod;     // waves resident per SIMD in this launch (PrioRotor), 0 / 1 = no rotation
 };
 
 // one env step of the K: everything between "action row in registers" and "outputs of step k issued".
@@ -893,7 +754,7 @@ __device__ __forceinline__ void many_step(const KParams& P, Shared& sh, const St
     if (POLICY) random_action(P.key_action, env, gstep, act);
     else { act[0] = arow.x; act[1] = arow.y; act[2] = arow.z; act[3] = arow.w; }
     StepOut out;
-    step_any<TASK, DRONE_CARRY_ROTOR != 0, PK, POLICY, (DRONE_SCALAR_RESET != 0) && !PK>(P, L, tile, act, env, gstep, out);
+    step_any<TASK, true, PK, POLICY>(P, L, tile, act, env, gstep, out);
     const bool ended = out.oob || out.trunc;
     any_target |= out.target_changed;
     any_end |= ended;
@@ -941,36 +802,17 @@ __device__ __forceinline__ void many_loop(const KParams& P, Shared& sh, const St
         a_cur = actp[0];
         a_nxt = actp[(size_t)min(1u, K - 1u) * m.act_stride];
     }
-    // short launches rotate the SIMD's priorities every step, long ones every second / eighth (PrioRotor)
-#if DRONE_PRIO_ROTATE_MANY
-    PrioRotor prio;
-    prio.init(m.prio_mod);
-#endif
     // step 0, peeled: the loop below is entered with step 0's stores behind the load of a_nxt, like every later entry
     many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, 0u, gstep0, i, block_base, any_target, any_end);
     for (uint32_t k = 1; k < K; k++) {
-#if DRONE_PRIO_ROTATE_MANY
-        prio.tick(k, K >= 64u ? 7u : K >= 16u ? 1u : 0u);
-#endif
         a_cur = a_nxt;
         if (!POLICY) a_nxt = actp[(size_t)min(k + 1u, K - 1u) * m.act_stride];  // the NEXT step's row: in flight during this step's arithmetic
         many_step<TASK, COMPACT, POLICY, FULL, PK>(P, sh, a, m, L, l0, l1, a_cur, k, gstep0 + k, i, block_base, any_target, any_end);
     }
-#if DRONE_PRIO_ROTATE_MANY
-    prio.done();
-#endif
 }
 
-#ifndef DRONE_MANY_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of the K-steps-per-launch kernel; 0 = unset
-#define DRONE_MANY_MIN_WAVES 0
-#endif
-#if DRONE_MANY_MIN_WAVES > 0
-#define DRONE_MANY_BOUNDS __launch_bounds__(kBlock, DRONE_MANY_MIN_WAVES)
-#else
-#define DRONE_MANY_BOUNDS __launch_bounds__(kBlock)
-#endif
 template <int TASK, bool COMPACT, bool POLICY, bool PK>
-__global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m) {
+__global__ __launch_bounds__(kBlock) void drone_step_many_kernel(StepArgs a, ManyArgs m) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
@@ -983,8 +825,7 @@ __global__ DRONE_MANY_BOUNDS void drone_step_many_kernel(StepArgs a, ManyArgs m)
     L.u = rotor_inputs(P, L.s.r);  // carried through the K steps (step_any<TASK, true>)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     bool any_target = false, any_end = false;
-    KParams Pv = P;  // (with -DDRONE_RK4_VGPR_CONSTS=1: the RK4's sixteen constants in vector registers — drone_lane.hpp; measured a wash, off)
-    if (!PK) rk4_consts_to_vgprs(Pv);
+    const KParams Pv = P;  // (as in the fused rollout: the full workgroups' loop sees a copy)
     if (block_base + kBlock <= n) many_loop<TASK, COMPACT, POLICY, true, PK>(Pv, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // workgroup-uniform
     else many_loop<TASK, COMPACT, POLICY, false, false>(P, sh, a, m, L, l0, l1, ctr.gstep, i, block_base, any_target, any_end);  // the last workgroup of a ragged shard (one workgroup: scalar form, less code)
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
@@ -1086,27 +927,13 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     a.nwg = 0;  // set by the launchers that deal chunks (step, rollout, step_many)
     a.sig = LaunchSig{nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
-#if !DRONE_PARAMS_IN_LDS && !DRONE_PARAMS_GLOBAL
+#if !DRONE_PARAMS_IN_LDS
     a.kp = *v.kp_host;
 #endif
     return a;
 }
 
 inline unsigned grid_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
-
-// How many waves of a launch of `nwg` workgroups share a SIMD while it runs: the dispatcher deals workgroups evenly over the
-// 256 CUs (tools/wg_census.py: exactly nwg / 256 per CU at every size tried), a workgroup puts kBlock / 64 / 4 waves on each of a
-// CU's four SIMDs, and `cap` is what the kernel's registers admit. DRONE_PRIO_MOD=<n> overrides (tuning; 1 = rotation off).
-inline uint32_t resident_waves_per_simd(uint32_t nwg, uint32_t cap) {
-    static const int forced = [] { const char* e = getenv("DRONE_PRIO_MOD"); return (e && *e) ? atoi(e) : -1; }();
-    if (forced >= 0) return (uint32_t)forced;
-    int cus = 256;
-    static const int dev_cus = [] { int d = 0, n = 0; return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256; }();
-    cus = dev_cus;
-    const uint32_t per_wg = kBlock / 64u >= 4u ? kBlock / 256u : 1u;
-    const uint32_t w = ((nwg + (uint32_t)cus - 1u) / (uint32_t)cus) * per_wg;
-    return w < cap ? w : cap;
-}
 
 // The packed-f32 RK4 form for the register-resident kernels: chosen per handle by the host (DeviceView::packed_rk4)
 inline bool use_packed(const DeviceView& v) { return DRONE_PK_RK4 && v.packed_rk4 != 0; }
@@ -1168,8 +995,7 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     const dim3 g(grid_for(v.n)), b(kBlock);
     a.nwg = g.x;
     const bool pk = use_packed(v);
-    const uint32_t prio_mod = resident_waves_per_simd(g.x, 4u);  // (every rollout instantiation takes 104-128 VGPRs: four waves per SIMD)
-#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon, prio_mod); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon, prio_mod); } while (0)
+#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon); } while (0)
     if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_HOVER);
     else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_SWARM);
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_RACE);
@@ -1186,7 +1012,6 @@ hipError_t launch_step_many(const DeviceView& v, int task, uint32_t gstep0, uint
     ManyArgs m;
     m.act = act; m.act_stride = act_stride; m.obs = obs; m.rew = rew; m.term = term; m.trunc = trunc;
     m.done_ids = done_ids; m.done_count = done_count; m.k_steps = k_steps;
-    m.prio_mod = resident_waves_per_simd(a.nwg, 2u);  // 176-204 VGPRs: two waves per SIMD
     const dim3 g(grid_for(v.n)), b(kBlock);
     const bool compact = done_ids != nullptr, policy = act == nullptr, pk = use_packed(v);
 #define DRONE_LAUNCH_MANY2(T, C, PO) do { if (pk) drone_step_many_kernel<T, C, PO, true><<<g, b, 0, s>>>(a, m); else drone_step_many_kernel<T, C, PO, false><<<g, b, 0, s>>>(a, m); } while (0)

@@ -25,7 +25,7 @@
 #ifndef DRONE_PK_DEFAULT
 #define DRONE_PK_DEFAULT 0
 #endif
-#if (defined(DRONE_PARAMS_IN_LDS) && DRONE_PARAMS_IN_LDS) || (defined(DRONE_PARAMS_GLOBAL) && DRONE_PARAMS_GLOBAL)  // the packed form takes its constants as SGPR pairs: kernarg constants only
+#if defined(DRONE_PARAMS_IN_LDS) && DRONE_PARAMS_IN_LDS  // the packed form takes its constants as SGPR pairs: kernarg constants only
 #undef DRONE_PK_RK4
 #define DRONE_PK_RK4 0
 #endif
@@ -335,38 +335,6 @@ DRONE_FN void rk4_substep(const KParams& P, Dyn& S, const float (&cmd)[4], const
     u0 = uf;
 }
 
-// Round 5, tried and not kept (the knob stays for the record). tools/micro/valu_pairs.hip: two waves of one SIMD that BOTH run
-// VOP3-encoded instructions with a scalar-register operand (v_fma_f32 v, s, v, v — how every "state + h * derivative" update and
-// every damping / gyroscopic term below is encoded while the constants sit in SGPRs) retire one instruction per 2.75 cycles
-// instead of 2.06, four waves one per 4.2 instead of 2.2; all-VGPR forms and the VOP2 forms with an SGPR in src0 run at the full
-// rate. 78 of the 275 instructions of a scalar RK4 substep are of that kind, fed by 16 constants. With DRONE_RK4_VGPR_CONSTS=1 the
-// register-resident kernels copy those 16 into VECTOR registers ahead of their step loop (same values, same instructions, other
-// operand class: bit-identical; the substep then holds no VOP3 + SGPR instruction at all). Measured, equal placement
-// (profiles/r05_ab/ab_vconst_*.txt): fused rollout -0.4 % at 2^20 envs, +0.9 % at 131 072, +1.3 % at 262 144; waypoint / race
-// +1.5 % / +0.6 % at 2^20 (136 / 138 VGPRs: a wave fewer per SIMD); step_many +-1 %. The conflict is between two waves that
-// issue such an instruction in the SAME window (the micro-benchmark's waves do nothing else); in a real stream one in five
-// instructions is of the kind and the partner's is usually not — the pair matrix of the same benchmark shows a restricted class
-// beside an unrestricted one co-issuing at the full rate. Not what holds the kernel at 2.5 cycles per instruction.
-#ifndef DRONE_RK4_VGPR_CONSTS
-#define DRONE_RK4_VGPR_CONSTS 0
-#endif
-DRONE_FN float vgpr_(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(x));  // opaque to the optimiser from here on: it can no longer prove the value uniform, so it stays in a VGPR
-#endif
-    return x;
-}
-DRONE_FN void rk4_consts_to_vgprs(KParams& Q) {
-#if DRONE_RK4_VGPR_CONSTS
-    Q.h = vgpr_(Q.h); Q.h_half = vgpr_(Q.h_half); Q.h_sixth = vgpr_(Q.h_sixth);
-    Q.hq = vgpr_(Q.hq); Q.hq_half = vgpr_(Q.hq_half); Q.hq_sixth = vgpr_(Q.hq_sixth);
-    Q.gxi = vgpr_(Q.gxi); Q.gyi = vgpr_(Q.gyi); Q.gzi = vgpr_(Q.gzi);
-    Q.kdx = vgpr_(Q.kdx); Q.kdy = vgpr_(Q.kdy); Q.kdz = vgpr_(Q.kdz);
-    Q.drag_m = vgpr_(Q.drag_m); Q.gravity = vgpr_(Q.gravity);
-    Q.e_half = vgpr_(Q.e_half); Q.e_full = vgpr_(Q.e_full);
-#endif
-}
-
 // all substeps of one env step, in the form the caller picked
 template <int TASK, bool PK>
 DRONE_FN void rk4_run(const KParams& P, Dyn& S, const float (&cmd)[4], const float (&wind)[3], RotorIn& u) {
@@ -398,14 +366,10 @@ DRONE_FN void lane_reset_from_draws(const KParams& P, Lane& L, const uint32_t (&
     // SPEC v5: (1, t) scaled to unit length by two Newton steps of 1/sqrt(n2) about 1 — 5 operations where the correctly
     // rounded sqrt + divide took 28 (two quarter-rate transcendentals among them) on the episode-end path
     const float n2 = fma_(t[0], t[0], fma_(t[1], t[1], fma_(t[2], t[2], 1.0f)));
-#if defined(DRONE_EXP_V4_EPISODE_END) && DRONE_EXP_V4_EPISODE_END  // MEASUREMENT ONLY (results differ from SPEC v5): the round-3 arithmetic, to price the change on one box
-    const float sc = 1.0f / sqrtf(n2);
-#else
     const float s1 = fma_(-0.5f, n2, 1.5f);
     const float m = (n2 * s1) * s1;
     const float s2 = fma_(-0.5f, m, 1.5f);
     const float sc = s1 * s2;
-#endif
     L.s.q[0] = sc;
     L.s.q[1] = t[0] * sc;
     L.s.q[2] = t[1] * sc;
@@ -437,34 +401,6 @@ DRONE_FN void lane_reset(const KParams& P, Lane& L, uint32_t env) {
     for (uint32_t k = 0; k < 5; k++) u[k] = rng_draw(b, k);
     lane_reset_from_draws<TASK, CARRY>(P, L, u);
 }
-
-#if defined(__HIP_DEVICE_COMPILE__)
-// The same for a whole wave in which SOME lanes' episodes ended (`ended`; every lane of the wave must call this), with the
-// six integer hashes of each ended lane computed on the SCALAR unit: an episode ends in about one lane-step of 146, so a
-// wave that has to run the reset at all has one or two lanes to reset, yet the vector form issues its ~50 hash instructions
-// for all 64. Here the wave walks the ballot mask, reads (env, episode) of one ended lane into SGPRs, hashes there
-// (s_mul_i32 / s_xor / s_lshr: they issue beside the other waves' VALU work) and hands the five draws to that lane with
-// one v_cndmask each. Integer arithmetic: bit-identical to the vector form by construction.
-template <int TASK, bool CARRY>
-__device__ __forceinline__ void lane_reset_wave(const KParams& P, Lane& L, uint32_t env, bool ended) {
-    uint32_t u[5] = {0u, 0u, 0u, 0u, 0u};
-    unsigned long long m = __ballot(ended);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    while (m) {  // wave-uniform
-        const int l = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t env_s = (uint32_t)__builtin_amdgcn_readlane((int)env, l), ep_s = (uint32_t)__builtin_amdgcn_readlane((int)L.episode, l);
-        const uint32_t b = rng_base(P.key_reset, env_s, ep_s);
-        const bool mine = lane == l;
-#pragma unroll
-        for (uint32_t k = 0; k < 5; k++) {
-            const uint32_t d = rng_draw(b, k);  // uniform: scalar unit
-            u[k] = mine ? d : u[k];             // one v_cndmask per draw hands it to its lane
-        }
-    }
-    if (ended) lane_reset_from_draws<TASK, CARRY>(P, L, u);
-}
-#endif
 
 // SPEC.md §2: the synthetic random policy.
 DRONE_FN void random_action(uint32_t key_action, uint32_t env, uint32_t gstep, float (&a)[4]) {
@@ -555,9 +491,9 @@ DRONE_FN void nearest_neighbour(const KParams& P, Other other, float& nn_d2, flo
 
 // SPEC.md §5 steps 5–9 (§10 steps 6–7 for the swarm task): distance, bounds,
 // reward, episode end and reset. `nn_d2` is read only by the swarm task.
-// SRESET (device only): the reset of ended episodes hashes on the scalar unit (lane_reset_wave) — every lane of the wave
-// must then be in this call together (the register-resident kernels' step loops are).
-template <int TASK, bool CARRY = false, bool SRESET = false>
+// (The reset draws of ended episodes hashed on the scalar unit, one ended lane at a time, was measured and not kept:
+// profiles/r06_pruned/.)
+template <int TASK, bool CARRY = false>
 DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx& ctx, float nn_d2, StepOut& out) {
     const float dist = target_dist(L);
     bool oob = !(fabsf(L.s.p[0]) <= P.bound) || !(fabsf(L.s.p[1]) <= P.bound) || !(fabsf(L.s.p[2]) <= P.bound);
@@ -618,11 +554,7 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
     out.perf = out.score = out.ep_return = out.ep_len = 0.0f;
     if (oob || trunc) {
         // SPEC v5: hover / swarm log the COUNT of steps within hover_radius (vec_log divides by the steps flown): no division here
-#if defined(DRONE_EXP_V4_EPISODE_END) && DRONE_EXP_V4_EPISODE_END
-        const float score = (TASK == DRONE_TASK_WAYPOINT || TASK == DRONE_TASK_RACE) ? (float)L.score_count : (float)L.score_count / (float)L.tick;
-#else
         const float score = (float)L.score_count;
-#endif
         float perf = score;
         if (TASK == DRONE_TASK_WAYPOINT || TASK == DRONE_TASK_RACE) perf = L.score_count >= 8u ? 1.0f : score * 0.125f;
         out.perf = perf;
@@ -630,24 +562,18 @@ DRONE_FN void lane_finish(const KParams& P, Lane& L, uint32_t env, const StepCtx
         out.ep_return = L.ep_return;
         out.ep_len = (float)L.tick;
         L.episode += 1u;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (!SRESET)
-#endif
-            lane_reset<TASK, CARRY>(P, L, env);
+        lane_reset<TASK, CARRY>(P, L, env);
         target_changed = true;
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (SRESET && __ballot(oob || trunc) != 0ull) lane_reset_wave<TASK, CARRY>(P, L, env, oob || trunc);
-#endif
     out.target_changed = target_changed;
 }
 
 // Single-agent tasks: the whole of SPEC.md §5 steps 1–9.
-template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT, bool INRANGE = false, bool SRESET = false>
+template <int TASK, bool CARRY = false, bool PK = DRONE_PK_DEFAULT, bool INRANGE = false>
 DRONE_FN void lane_step(const KParams& P, Lane& L, const float (&act)[4], uint32_t env, uint32_t gstep, StepOut& out) {
     StepCtx ctx;
     lane_integrate<TASK, CARRY, PK, INRANGE>(P, L, act, env, gstep, ctx);
-    lane_finish<TASK, CARRY, SRESET>(P, L, env, ctx, 0.0f, out);
+    lane_finish<TASK, CARRY>(P, L, env, ctx, 0.0f, out);
 }
 
 // SPEC.md §7

@@ -1,23 +1,51 @@
-"""The compile-time knobs of drone_kernels.hip that tools and A/B logs refer to must keep BUILDING (gfx950 cross-compile, no
-GPU needed): round 4 found -DDRONE_PARAMS_GLOBAL=1 broken since the packed RK4 went in. Compiled in parallel, device code
-only, output discarded; the variants' RESULTS are checked where they are used (tests/test_parity_gpu.py builds and runs the
-LDS-constants variant, tools/ab_step.py times the others)."""
+"""Two checks of drone_kernels.hip that need hipcc but no GPU (gfx950 cross-compile).
+
+1. The compile-time variants a test, a tool or a fallback build still selects must keep BUILDING (round 4 found one broken
+   for two rounds). Their RESULTS are checked where they are used: tests/test_parity_gpu.py builds and runs the LDS-constants
+   variant on the GPU box, tools/stamps.py the stamped one, tools/r06_flake.sh the build without kernarg preloading.
+2. The ISA of every shipped kernel instantiation is the MEASURED one: round 6 pruned the measured-dead
+   knobs out of the source and re-landed the peer-store stop word as instantiations of their own, under the rule that not one
+   instruction and not one descriptor field of the kernels the round-5 profiles measured may move. tests/golden/
+   isa_shipped_r05.json is tools/isa_digest.py's digest of the round-5 library's listing (sha256 of each kernel's
+   instruction stream with labels renumbered, its descriptor, register counts). New kernels may appear; none may change or go.
+   A deliberate kernel change regenerates the golden file — and owes TUNING.md a measurement.
+"""
+import json
 import os
 import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "drone_amd", "csrc")
-BASE = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
-        "-mllvm", "-amdgpu-kernarg-preload-count=12", "--cuda-device-only", "-c", "drone_kernels.hip", "-o", "/dev/null"]
-VARIANTS = ["-DDRONE_PARAMS_GLOBAL=1", "-DDRONE_STAMPS=1", "-DDRONE_EARLY_ARGS=0", "-DDRONE_EARLY_ARGS=3", "-DDRONE_SCALAR_RESET=1", "-DDRONE_STEP_TILES=2 -DDRONE_STEP_WAVE_OUTPUTS=1",
-            "-DDRONE_PK_RK4=0 -DDRONE_CARRY_ROTOR=0"]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+COMMON = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "--cuda-device-only"]
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=12"]  # drone_amd/csrc/Makefile PRELOAD
+VARIANTS = [("-DDRONE_STAMPS=1", PRELOAD), ("-DDRONE_PARAMS_IN_LDS=1", PRELOAD), ("-DDRONE_PK_RK4=0", PRELOAD), ("-DDRONE_EARLY_ARGS=0", [])]
 
 
-def test_every_documented_knob_still_compiles():
-    procs = [(v, subprocess.Popen(BASE + v.split(), cwd=SRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for v in VARIANTS]
+def test_every_variant_somebody_selects_still_compiles_and_the_shipped_isa_is_the_measured_one(tmp_path):
+    procs = [(v, subprocess.Popen(COMMON + pre + v.split() + ["-c", "drone_kernels.hip", "-o", "/dev/null"], cwd=SRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+             for v, pre in VARIANTS]
+    listing = str(tmp_path / "drone_kernels.s")
+    shipped = subprocess.run(COMMON + PRELOAD + ["-S", "-o", listing, "drone_kernels.hip"], cwd=SRC, capture_output=True, text=True, timeout=900)
     failed = []
     for v, p in procs:
         so, se = p.communicate(timeout=900)
         if p.returncode != 0:
             failed.append(f"{v}: {se[-600:]}")
     assert not failed, "\n".join(failed)
+    assert shipped.returncode == 0, shipped.stderr[-800:]
+
+    import isa_digest
+
+    now = isa_digest.digest(listing)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "isa_shipped_r05.json")))["kernels"]
+    gone = sorted(set(want) - set(now))
+    changed = sorted(k for k in want if k in now and now[k] != want[k])
+    assert not gone, f"kernels of the measured build that no longer exist: {gone}"
+    assert not changed, "kernels whose ISA or descriptor differs from the measured build: " + "; ".join(
+        f"{k}: " + ", ".join(f"{f} {want[k][f]} -> {now[k][f]}" for f in want[k] if want[k][f] != now[k][f] and not f.endswith("sha256")) for k in changed[:8])
+    assert len(want) == 96
+    # what is new must be named as such: the peer-store instantiations (LaunchSig::stop) and nothing else
+    extra = sorted(set(now) - set(want))
+    assert all("_peer_kernel" in k for k in extra), extra
