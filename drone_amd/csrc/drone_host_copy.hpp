@@ -21,6 +21,9 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 namespace drone {
 
@@ -29,7 +32,9 @@ public:
     typedef void (*Fn)(void* ctx, int part, int parts);
 
     // helpers: pool threads besides the caller. DRONE_HOST_COPY_THREADS=<total threads per job, caller included>; default: half
-    // the machine's hardware threads, at most 8; 1 (or 0) = no pool: everything runs on the caller
+    // the CPUs this process may run on (its affinity mask, not the machine: a vec-env worker pinned to four cores gets two
+    // threads), at most 8; 1 (or 0) = no pool: everything runs on the caller. Several worker processes on one box each have
+    // a pool: give them DRONE_HOST_COPY_THREADS ~ cores / workers
     static CopyPool& get() {
         static CopyPool pool;
         return pool;
@@ -51,15 +56,19 @@ public:
         }
         return true;
     }
-    // run part 0 here, then wait for the helpers; `watch(watch_ctx)` is called every few microseconds of that wait (and once
-    // before it) — the caller's chance to tell the helpers that what they are waiting for will never come, or already has
+    // run part 0 here, then wait for the helpers; `watch(watch_ctx)` is called every few microseconds of that wait — the
+    // caller's chance to tell the helpers that what they are waiting for will never come, or already has. (Part 0 runs BEFORE
+    // the first watch: a job whose part 0 can stall must look for itself — drone_vec.cpp copy_outputs_part does.) A helper
+    // that has been descheduled (an oversubscribed or quota-limited box) is waited for politely: after ~50 us of spinning the
+    // caller yields its time slice between looks.
     void finish(void (*watch)(void*) = nullptr, void* watch_ctx = nullptr) {
         fn_(ctx_, 0, parts());
         const int want = (int)workers_.size();
         unsigned spins = 0;
         while (done_.load(std::memory_order_acquire) < want) {
-            if (watch && (spins++ & 255u) == 0) watch(watch_ctx);
-            cpu_relax();
+            if (watch && (spins & 255u) == 0) watch(watch_ctx);
+            if (++spins > 4096u) std::this_thread::yield();
+            else cpu_relax();
         }
         busy_.store(false, std::memory_order_release);
     }
@@ -78,7 +87,11 @@ public:
 
 private:
     CopyPool() {
-        const int hw = (int)std::thread::hardware_concurrency();
+        int hw = (int)std::thread::hardware_concurrency();
+#if defined(__linux__)
+        cpu_set_t mask;  // what this PROCESS may use: affinity masks and cpusets shrink it, hardware_concurrency does not notice
+        if (sched_getaffinity(0, sizeof(mask), &mask) == 0 && CPU_COUNT(&mask) > 0 && CPU_COUNT(&mask) < hw) hw = CPU_COUNT(&mask);
+#endif
         int total = hw >= 16 ? 8 : hw >= 4 ? hw / 2 : 1;  // half the machine's threads, at most eight (measured: 65 536 envs 211 us per step with four, 166 with eight; profiles/r05_ab/host_transports.txt)
         const char* e = getenv("DRONE_HOST_COPY_THREADS");
         if (e && *e) total = atoi(e);

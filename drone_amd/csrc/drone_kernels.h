@@ -48,13 +48,23 @@ struct DeviceView {
 //   wg_done: one word per 256-drone chunk, in ENV order, in pinned host memory. A workgroup of the per-step kernel stores
 //     wg_done_value there once its chunk's rows have been acknowledged (same drain + release), so that host threads can
 //     copy finished chunks to the caller's memory while the rest of the kernel is still writing over PCIe.
+// A stream-side wait of the handshake that gives up (a dead or silent peer) raises the handle's STOP word; the launches a
+//   caller has queued behind that wait must then store nothing — the root may still be reading the batch they would
+//   overwrite — and publish nothing (round 6; ADVICE r4 / VERDICT r5 item 2). The word lives in the handle's peer block in
+//   HBM next to the arrival counter (`arrive[kPeerStopWord]`; the kernel boundary behind the wait kernel publishes it), and
+//   only the PEER instantiations of the reset / step / rollout kernels look at it (`peer` = 1 selects them): every other
+//   handle launches kernels that are instruction for instruction those of round 5 (tests/test_build_variants.py).
 struct LaunchSig {
     uint32_t* ack_flag;    // host memory shared by the ranks (device-mapped), or null
     uint32_t* post_flag;   // likewise, or null
-    uint32_t* arrive;      // HBM: workgroups of this launch that have released their stores; zero between launches
+    uint32_t* arrive;      // HBM, the handle's peer block: [0] workgroups of this launch that have released their stores (zero between launches), [kPeerStopWord] the stop word
     uint32_t* wg_done;     // pinned host memory (device-mapped): [chunks] words, or null
     uint32_t ack_value, post_value, wg_done_value;
+    uint32_t peer;         // host side only: 1 = launch the peer instantiation (arrive is then non-null). Sits in what used to be padding: the layout the kernels see is round 5's
 };
+static_assert(sizeof(LaunchSig) == 48, "LaunchSig is part of every kernel's argument block: its layout is frozen (tests/test_build_variants.py)");
+constexpr uint32_t kPeerStopWord = 8;   // word index of the stop word in the peer block (its own 32-byte sector)
+constexpr size_t kPeerBlockBytes = 64;
 
 #ifndef DRONE_BLOCK  // workgroup size (tuning knob; multiple of 64)
 #define DRONE_BLOCK 256
@@ -81,8 +91,8 @@ hipError_t launch_log_reduce(const DeviceView& v, double* partials, int max_grid
 // sleeping between polls; the wave gives up after `budget_ticks` of the 100 MHz real-time counter and sets *err
 // (host-mapped) instead of spinning for ever — and returns AT ONCE when *err is already set (an earlier wait of this
 // handle gave up: the waits a caller has queued behind it must not spin their budgets one after the other).
-// ONE launch for all the ranks waited for.
+// ONE launch for all the ranks waited for. `stop`: the handle's stop word in HBM (LaunchSig), raised together with *err.
 hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s);
-hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s);
+hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, uint32_t* stop, unsigned long long budget_ticks, hipStream_t s);
 
 }  // namespace drone

@@ -461,6 +461,12 @@ __device__ __forceinline__ void advance_counters(const StepArgs& a, const Counte
 // Peer-store exchange: the handshake's two publications from inside the launch that writes the outputs (LaunchSig).
 // ack: the root's stream has reached this launch, so whatever consumed the previous batch is done (stream order); one
 // relaxed system-scope store by the first lane of the grid — it carries no data, so no fence.
+// a stream-side wait of this handle has given up (LaunchSig: the stop word): the handshake is broken — the root may still be reading
+// the batch this launch would overwrite, or nobody is left to read it. Peer instantiations only; launch-uniform.
+__device__ __forceinline__ uint32_t peer_stop_word(const StepArgs& a) {
+    return __hip_atomic_load(a.sig.arrive + kPeerStopWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool peer_stopped(const StepArgs& a) { return __builtin_amdgcn_readfirstlane(peer_stop_word(a)) != 0u; }
 __device__ __forceinline__ void peer_ack(const StepArgs& a) {
     if (a.sig.ack_flag && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(a.sig.ack_flag, a.sig.ack_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -514,7 +520,10 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uin
 #define DRONE_STEP_PRE_PARAMS const float4* __restrict__ pre_planes, const float* __restrict__ pre_act, const uint32_t* __restrict__ pre_ctr, uint32_t pre_n, uint32_t pre_n_pad, \
                               uint32_t pre_order, uint32_t pre_nwg, uint32_t pre_gstep, uint32_t pre_slot
 
-template <int TASK, bool COMPACT, int MEM, bool DT>
+// PEER: the handle is in a peer-store exchange with stream-side waits (LaunchSig::peer) — the launch first looks at the stop word.
+// A trailing template argument of the kernel itself, so that the PEER = false instantiations are, instruction for instruction,
+// the kernels round 5 measured (moving the body into a function shared by two kernels reordered a handful of instructions).
+template <int TASK, bool COMPACT, int MEM, bool DT, bool PEER = false>
 __global__ __launch_bounds__(kBlock, kStepMinWaves) void drone_step_kernel(DRONE_STEP_PRE_PARAMS, StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -544,6 +553,7 @@ __global__ __launch_bounds__(kBlock, kStepMinWaves) void drone_step_kernel(DRONE
     __builtin_amdgcn_sched_barrier(0);
 #endif
     if (COMPACT && blockIdx.x == 0 && threadIdx.x == 0) a.v.done_count[done_slot ^ 1u] = 0u;  // arm the next step launch's counter
+    if (PEER && peer_stopped(a)) return;  // nothing is stored, nothing published
     peer_ack(a);
     const uint32_t i = block_base + threadIdx.x;
     const bool valid = i < n;
@@ -623,13 +633,14 @@ __global__ __launch_bounds__(kBlock, kStepMinWaves) void drone_step_kernel(DRONE
 // =====================================================================
 // vec_reset (SPEC.md §6). Grid covers n_pad so the padding lanes are valid too.
 // =====================================================================
-template <int TASK>
+template <int TASK, bool PEER = false>
 __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
     const uint32_t n = a.v.n, np = a.v.stride;
     const uint32_t block_base = blockIdx.x * kBlock;
     const uint32_t i = block_base + threadIdx.x;
+    if (PEER && peer_stopped(a)) return;
     peer_ack(a);
     Lane L;
     L.episode = 0u;
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(kBlock) void drone_reset_kernel(StepArgs a) {
 // whole horizon; actions come from the counter RNG; HBM is touched once on
 // the way in and once on the way out.
 // =====================================================================
-template <int TASK, bool PK>
+template <int TASK, bool PK, bool PEER = false>
 __global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint32_t horizon) {
     __shared__ Shared sh;
     const KParams& P = DRONE_PARAMS(sh, a);
@@ -666,6 +677,11 @@ __global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint3
     L.u = rotor_inputs(P, L.s.r);  // carried from here on (step_any<TASK, true>: -18 operations per substep, bit-identical)
     float4 l0 = a.v.cold[i], l1 = a.v.cold[np + i];
     const uint32_t env = P.env_offset + i;
+    // the stop word: loaded here, beside the state, and looked at behind the step loop — an early exit up here makes every wave of the
+    // launch wait for this load ahead of the loop's first instruction (round 5: +2.5 % at 2^20 envs; behind the loop +0.5 %,
+    // profiles/r05_ab/ab_stop_rollout_*.txt — and that only in the peer instantiation)
+    uint32_t stop_word = 0u;
+    if (PEER) stop_word = peer_stop_word(a);
     peer_ack(a);
     float rsum = 0.0f;
     bool any_term = false, any_trunc = false, any_target = false;
@@ -694,6 +710,7 @@ __global__ __launch_bounds__(kBlock) void drone_rollout_kernel(StepArgs a, uint3
         row[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
+    if (PEER && __builtin_amdgcn_readfirstlane(stop_word) != 0u) return;  // a wait of this handle gave up before this launch: nothing is stored or published
     // padding lanes [n, n_pad) own their plane slots (see the step kernel); rare updates go out as whole lines
     store_lane<TASK>(a.v.planes, a.v.n_pad, i, L, lane_bit(whole_lines(__ballot(any_target), a.v.line_complete)), dt);
     out_store(valid ? &a.v.rew[i] : &a.v.pad_sink[threadIdx.x], rsum);
@@ -903,7 +920,7 @@ __global__ __launch_bounds__(64) void drone_flag_post_kernel(uint32_t* flag, uin
 // peer), and a caller that does not sync every launch has queued every later step's wait behind it — each would
 // otherwise spin its full budget in turn. The error word is loaded together with the flags (both live in
 // host memory: one PCIe round trip either way).
-__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks) {
+__global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, uint32_t* stop, unsigned long long budget_ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         const uint32_t failed = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -912,7 +929,10 @@ __global__ __launch_bounds__(64) void drone_flag_wait_kernel(const uint32_t* fla
             if (r != skip) ok = ok && (int32_t)(__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) >= 0;
         if (__all(ok) || failed != 0u) break;  // wave-uniform (err is one address: every lane read the same word)
         if (__builtin_amdgcn_s_memrealtime() - t0 > budget_ticks) {  // a dead peer: report, do not hang the queue
-            if (threadIdx.x == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // what the launches queued behind this wait read from HBM (the kernel boundary publishes it)
+            }
             break;
         }
         __builtin_amdgcn_s_sleep(64);
@@ -925,7 +945,7 @@ StepArgs make_args(const DeviceView& v, uint32_t gstep) {
     a.gstep = gstep;
     a.done_slot = 0;
     a.nwg = 0;  // set by the launchers that deal chunks (step, rollout, step_many)
-    a.sig = LaunchSig{nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    a.sig = LaunchSig{nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u};
     a.flags_aligned = ((reinterpret_cast<uintptr_t>(v.term) & 15u) == 0 ? 1u : 0u) | ((reinterpret_cast<uintptr_t>(v.trunc) & 15u) == 0 ? 2u : 0u);
 #if !DRONE_PARAMS_IN_LDS
     a.kp = *v.kp_host;
@@ -950,6 +970,13 @@ hipError_t launch_reset(const DeviceView& v, int task, hipStream_t s, const Laun
     const dim3 g(v.n_pad / kBlock), b(kBlock);
     StepArgs a = make_args(v, 0);
     if (sig) a.sig = *sig;
+    if (a.sig.peer) {
+        if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM, true><<<g, b, 0, s>>>(a);
+        else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE, true><<<g, b, 0, s>>>(a);
+        else if (task == DRONE_TASK_WAYPOINT) drone_reset_kernel<DRONE_TASK_WAYPOINT, true><<<g, b, 0, s>>>(a);
+        else drone_reset_kernel<DRONE_TASK_HOVER, true><<<g, b, 0, s>>>(a);
+        return hipGetLastError();
+    }
     if (task == DRONE_TASK_SWARM) drone_reset_kernel<DRONE_TASK_SWARM><<<g, b, 0, s>>>(a);
     else if (task == DRONE_TASK_RACE) drone_reset_kernel<DRONE_TASK_RACE><<<g, b, 0, s>>>(a);
     else if (task == DRONE_TASK_WAYPOINT) drone_reset_kernel<DRONE_TASK_WAYPOINT><<<g, b, 0, s>>>(a);  // its tiles carry the wind plane
@@ -967,6 +994,16 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     const bool compact = v.done_ids != nullptr;
     const int mem = (int)((v.order >> 2) & 3u);  // bit 0: non-temporal action loads, bit 1: non-temporal state loads (DeviceView::order bits 2, 3)
 #define DRONE_PRE_ARGS a.v.planes, a.v.act, a.v.ctr, a.v.n, a.v.n_pad, a.v.order, a.nwg, a.gstep, a.done_slot
+    const bool dt = v.derived_target != 0;
+    if (a.sig.peer) {  // the peer instantiations (stop word): task x compact x layout, no load hints
+#define DRONE_LAUNCH_PEER2(T, D) do { if (compact) drone_step_kernel<T, true, 0, D, true><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); else drone_step_kernel<T, false, 0, D, true><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a); } while (0)
+        if (task == DRONE_TASK_HOVER) { if (dt) DRONE_LAUNCH_PEER2(DRONE_TASK_HOVER, true); else DRONE_LAUNCH_PEER2(DRONE_TASK_HOVER, false); }
+        else if (task == DRONE_TASK_SWARM) { if (dt) DRONE_LAUNCH_PEER2(DRONE_TASK_SWARM, true); else DRONE_LAUNCH_PEER2(DRONE_TASK_SWARM, false); }
+        else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_PEER2(DRONE_TASK_RACE, false);
+        else DRONE_LAUNCH_PEER2(DRONE_TASK_WAYPOINT, false);
+#undef DRONE_LAUNCH_PEER2
+        return hipGetLastError();
+    }
 #define DRONE_LAUNCH_STEP3(T, C, D)                                                          \
     do {                                                                                     \
         if (mem == 0) drone_step_kernel<T, C, 0, D><<<g, b, 0, s>>>(DRONE_PRE_ARGS, a);      \
@@ -976,7 +1013,6 @@ hipError_t launch_step(const DeviceView& v, int task, uint32_t gstep, uint32_t d
     } while (0)
 #define DRONE_LAUNCH_STEP2(T, D) do { if (compact) DRONE_LAUNCH_STEP3(T, true, D); else DRONE_LAUNCH_STEP3(T, false, D); } while (0)
 #define DRONE_LAUNCH_STEP(T) DRONE_LAUNCH_STEP2(T, false)
-    const bool dt = v.derived_target != 0;
     if (task == DRONE_TASK_HOVER) { if (dt) DRONE_LAUNCH_STEP2(DRONE_TASK_HOVER, true); else DRONE_LAUNCH_STEP(DRONE_TASK_HOVER); }
     else if (task == DRONE_TASK_SWARM) { if (dt) DRONE_LAUNCH_STEP2(DRONE_TASK_SWARM, true); else DRONE_LAUNCH_STEP(DRONE_TASK_SWARM); }
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_STEP(DRONE_TASK_RACE);
@@ -995,7 +1031,12 @@ hipError_t launch_rollout(const DeviceView& v, int task, uint32_t gstep0, uint32
     const dim3 g(grid_for(v.n)), b(kBlock);
     a.nwg = g.x;
     const bool pk = use_packed(v);
-#define DRONE_LAUNCH_ROLLOUT(T) do { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon); } while (0)
+    const bool peer = a.sig.peer != 0;
+#define DRONE_LAUNCH_ROLLOUT(T)                                                                                                                              \
+    do {                                                                                                                                                     \
+        if (peer) { if (pk) drone_rollout_kernel<T, true, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false, true><<<g, b, 0, s>>>(a, horizon); } \
+        else { if (pk) drone_rollout_kernel<T, true><<<g, b, 0, s>>>(a, horizon); else drone_rollout_kernel<T, false><<<g, b, 0, s>>>(a, horizon); }               \
+    } while (0)
     if (task == DRONE_TASK_HOVER) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_HOVER);
     else if (task == DRONE_TASK_SWARM) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_SWARM);
     else if (task == DRONE_TASK_RACE) DRONE_LAUNCH_ROLLOUT(DRONE_TASK_RACE);
@@ -1041,9 +1082,9 @@ hipError_t launch_flag_post(uint32_t* flag, uint32_t value, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, unsigned long long budget_ticks, hipStream_t s) {
+hipError_t launch_flag_wait(const uint32_t* flags, uint32_t count, uint32_t skip, uint32_t want, uint32_t* err, uint32_t* stop, unsigned long long budget_ticks, hipStream_t s) {
     drop_stale_error();
-    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flags, count, skip, want, err, budget_ticks);
+    drone_flag_wait_kernel<<<dim3(1), dim3(64), 0, s>>>(flags, count, skip, want, err, stop, budget_ticks);
     return hipGetLastError();
 }
 

@@ -146,9 +146,9 @@ struct DroneVec {
     void* pinned_blocks[64];
     int n_pinned_blocks;
     char variant[448];   // drone_vec_variant
-    // round 5: the sweep order / load hints of an HBM-bound handle are MEASURED on the box it runs on, under the workload it
-    // runs, during its first few hundred real steps (struct SweepTune); the footprint table of drone_vec_init only nominates
-    // the candidates and stands until the measurement is complete
+    // DRONE_AUTOTUNE=1: the sweep order / load hints of an HBM-bound handle are measured on the box it runs on, under the
+    // workload it runs, during its first few hundred real steps (struct SweepTune); null otherwise — the footprint table of
+    // drone_vec_init decides (round 6: opt-in, the measurement re-derived the table in 12 of 12 logged cases)
     struct SweepTune* tune;
     size_t touched_mib;  // MiB one step touches (the footprint the table is indexed by)
     // sticky status: the first failure of any call on this handle (drone_vec_status)
@@ -336,21 +336,36 @@ HostStamps g_stamps;
 #define HOST_STAMP(what) ((void)0)
 #endif
 
+// what the thread that called the step knows about the stream while the outputs are being delivered: drained = everything has
+// landed, nobody needs to look at the words any more; failed = everybody must stop
+void poll_stream(void* ctx) {
+    DroneVec* h = static_cast<DroneVec*>(ctx);
+    const hipError_t q = hipStreamQuery(h->stream);
+    if (q == hipSuccess) __atomic_store_n(&h->stream_idle, 1, __ATOMIC_RELEASE);
+    else if (q != hipErrorNotReady) { (void)hipGetLastError(); __atomic_store_n(&h->copy_abort, 1, __ATOMIC_RELEASE); }
+}
+
 // The step's outputs, while the kernel runs: this thread owns a contiguous share of the chunks and copies every run of
 // chunks whose words have turned to the step's sequence number. The words are an accelerator, not the contract: once the
-// calling thread has seen the stream drain (stream_idle) everything has landed and the rest is copied without looking.
+// stream is known to have drained (stream_idle) everything has landed and the rest is copied without looking. Part 0 runs on
+// the CALLING thread (CopyPool::finish) ahead of the pool's own watch: while it is stalled it polls the stream itself, so a
+// chunk word that never comes (a failed launch, a fault) ends in an error instead of a spin.
 void copy_outputs_part(void* ctx, int part, int parts) {
     DroneVec* v = static_cast<DroneVec*>(ctx);
     const uint32_t c0 = (uint32_t)((uint64_t)v->n_wg * (uint32_t)part / (uint32_t)parts), c1 = (uint32_t)((uint64_t)v->n_wg * (uint32_t)(part + 1) / (uint32_t)parts);
     const uint32_t seq = v->wg_seq;
     bool idle = false;
+    uint32_t stalls = 0;
     for (uint32_t c = c0; c < c1;) {
         uint32_t e = c;
         while (e < c1 && (idle || __atomic_load_n(v->h_wg_done + e, __ATOMIC_ACQUIRE) == seq)) e++;
         if (e == c) {
             if (__atomic_load_n(&v->copy_abort, __ATOMIC_ACQUIRE)) return;
             if (__atomic_load_n(&v->stream_idle, __ATOMIC_ACQUIRE)) idle = true;
-            else CopyPool::cpu_relax();
+            else {
+                if (part == 0 && (++stalls & 255u) == 0) poll_stream(v);
+                CopyPool::cpu_relax();
+            }
             continue;
         }
 #if DRONE_HOST_STAMPS
@@ -446,16 +461,7 @@ bool enqueue_host_outputs(DroneVec* v) {
 // the calling thread's part of a threaded copy-out, then the wait for the helpers — during which it keeps an eye on the stream:
 // drained = everything has landed, the helpers need not look at the words any more; failed = they must stop
 bool finish_threaded_copy(DroneVec* v) {
-    CopyPool& pool = CopyPool::get();
-    struct Watch {
-        static void poll(void* ctx) {
-            DroneVec* h = static_cast<DroneVec*>(ctx);
-            const hipError_t q = hipStreamQuery(h->stream);
-            if (q == hipSuccess) __atomic_store_n(&h->stream_idle, 1, __ATOMIC_RELEASE);
-            else if (q != hipErrorNotReady) { (void)hipGetLastError(); __atomic_store_n(&h->copy_abort, 1, __ATOMIC_RELEASE); }
-        }
-    };
-    pool.finish(Watch::poll, v);
+    CopyPool::get().finish(poll_stream, v);
     v->copy_started = false;
     if (__atomic_load_n(&v->copy_abort, __ATOMIC_ACQUIRE)) { set_err("the stream failed while the step's outputs were being delivered"); return false; }
     return true;
@@ -707,8 +713,11 @@ struct Gather {
     // one-wave launches of their own. DRONE_PEER_INKERNEL=0 keeps the separate launches (A/B; also what the host-side and
     // hipStreamWriteValue32 forms use).
     bool in_kernel = true;
-    uint32_t* d_arrive = nullptr;        // HBM: the arrival counter of the in-kernel post (non-root ranks)
+    uint32_t* d_arrive = nullptr;        // HBM, the peer block (drone_kernels.h LaunchSig): [0] the arrival counter of the in-kernel post, [kPeerStopWord] the stop word
+                                         // a stream-side wait raises when it gives up; allocated whenever the waits run on the stream
     uint32_t launch_posts = 0;           // non-root: the round the LAST output-writing launch publishes by itself when it ends (0: none)
+    bool launched = false;               // an output-writing launch has gone out since the last drone_vec_gather: the next one must be the gather
+    uint32_t own_order = 0;              // the handle's sweep order / load hints before the exchange (the peer instantiations carry no load hints)
     float* own_obs = nullptr; float* own_rew = nullptr; unsigned char* own_term = nullptr; unsigned char* own_trunc = nullptr;  // the handle's output bindings before the exchange took them over
 };
 
@@ -727,6 +736,8 @@ struct SweepTune {
 
 namespace {
 
+void write_variant(DroneVec* v, const char* tuned);
+
 void gather_destroy(DroneVec* v) {
     Gather* g = v->gather;
     if (!g) return;
@@ -737,6 +748,7 @@ void gather_destroy(DroneVec* v) {
     if (g->peer) {  // give the handle its own output buffers back, then drop the mappings
         if (v->stream) (void)hipStreamSynchronize(v->stream);
         v->dv.obs = g->own_obs; v->dv.rew = g->own_rew; v->dv.term = g->own_term; v->dv.trunc = g->own_trunc;
+        if (v->dv.order != g->own_order) { v->dv.order = g->own_order; write_variant(v, nullptr); }
         for (int k = 0; k < 4; k++)
             if (g->peer_base[k]) (void)hipIpcCloseMemHandle(g->peer_base[k]);
         if (g->flags_registered) host_unregister(const_cast<uint32_t*>(g->flags), v, "peer-store flag page");
@@ -779,7 +791,7 @@ long peer_timeout_ms() {
 // flags [first, first + count) except `skip` (-1: none) have all reached `want`
 bool peer_wait_ge(DroneVec* v, Gather* g, int first, int count, int skip, uint32_t want) {
     if (g->gpu_waits) {  // one launch, one lane per flag, polling the shared words from the stream; gives up after the budget and says so in *d_err
-        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags) + first, (uint32_t)count, (uint32_t)skip, want, g->d_err, g->budget_ticks, v->stream), return false);
+        HIP_TRY(launch_flag_wait(reinterpret_cast<const uint32_t*>(g->d_flags) + first, (uint32_t)count, (uint32_t)skip, want, g->d_err, g->d_arrive + kPeerStopWord, g->budget_ticks, v->stream), return false);
         return true;
     }
     HIP_TRY(hipStreamSynchronize(v->stream), return false);
@@ -843,18 +855,28 @@ bool peer_check_err(Gather* g) {
 bool peer_before_launch(DroneVec* v, LaunchSig* sig) {
     Gather* g = v->gather;
     if (!g || !g->peer) return true;
+    if (!peer_check_err(g)) return false;  // a stream-side wait of an earlier round gave up: that is what the caller must hear first
+    // One batch per round: a second output-writing launch before the gather would find its wait already satisfied and overwrite
+    // this rank's rows in the root's HBM while the root may be consuming the round the first launch announced.
+    if (g->launched) {
+        set_err("peer-store exchange: drone_vec_gather must follow every reset / step / rollout while the exchange is active (two launches without a gather in between)");
+        return false;
+    }
     const bool in_kernel = g->in_kernel && g->gpu_waits && !g->stream_writes;
+    if (g->gpu_waits) {  // launches queued behind a wait that gives up must store nothing: the peer instantiations read the stop word
+        sig->peer = 1u;
+        sig->arrive = g->d_arrive;
+    }
+    g->launched = true;
     if (g->rank != g->root) {
         g->launch_posts = 0;
         if (in_kernel) {
             sig->post_flag = reinterpret_cast<uint32_t*>(g->d_flags + 4 * g->rank);
             sig->post_value = g->seq + 1u;
-            sig->arrive = g->d_arrive;
             g->launch_posts = sig->post_value;
         }
     }
     if (g->seq == 0) return true;
-    if (!peer_check_err(g)) return false;
     if (g->rank == g->root) {
         if (g->acked != g->seq) {
             if (in_kernel) {
@@ -868,6 +890,14 @@ bool peer_before_launch(DroneVec* v, LaunchSig* sig) {
         return true;
     }
     return peer_wait_ge(v, g, g->world, 1, -1, g->seq);
+}
+
+// the launch peer_before_launch prepared did not go out: nothing will publish its round
+void peer_launch_failed(DroneVec* v) {
+    Gather* g = v->gather;
+    if (!g || !g->peer) return;
+    g->launch_posts = 0;
+    g->launched = false;
 }
 
 // drone_vec_variant's text; `tuned`: " autotuned=1 table=8 tried=o8:170.1,o0:178.8,o6:170.3" once the handle has measured the candidates (SweepTune below)
@@ -1296,14 +1326,15 @@ DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, un
         uint32_t order = mib <= 400 ? 1u : mib <= 450 ? 0u : mib <= rev_to ? 6u : mib <= 900 ? 0u : 6u;
         if (hover_dt && mib > 400 && mib <= 1100) order = 8u;
         v->dv.order = (o && *o) ? (uint32_t)atoi(o) : order;
-        // Beyond 400 MiB the table's entry is only the FIRST candidate: the adopted differences between the orders there
-        // (-1.8 ... -3 % at 2^22 envs) are smaller than the spread of one binary across boxes of the pool (+-5 %), and the
-        // driver's box disagreed with the table at 2^22 against 2^23. The handle's own steps 161 ... 256 time
-        // the candidates on this box, on its own buffers, under its own workload (SweepTune). Not for a forced order, host
-        // buffers (PCIe-bound at these sizes) or DRONE_AUTOTUNE=0.
+        // DRONE_AUTOTUNE=1 (opt-in since round 6): beyond 400 MiB the handle's own steps 161 ... 256 time the table's entry and
+        // its neighbours on this box, on its own buffers, under its own workload (SweepTune), and the fastest becomes the
+        // handle's order. Round 5 ran this by default and logged 12 of 12 cases on three boxes in which the measurement picked
+        // exactly the table's entry, at a cost of 0.1 ... 0.8 % (profiles/r05_ab/autotune_online_box*.txt):
+        // the table stands, the measurement is there for a box or a workload someone has reason to distrust it on. Not for a
+        // forced order or host buffers (PCIe-bound at these sizes).
         const char* at = getenv("DRONE_AUTOTUNE");
         v->touched_mib = mib;
-        if (mib > 400 && !(o && *o) && !v->host_buffers && !(at && *at && atoi(at) == 0)) {
+        if (mib > 400 && !(o && *o) && !v->host_buffers && at && *at && atoi(at) != 0) {
             v->tune = new (std::nothrow) SweepTune();
             if (v->tune) {
                 v->tune->table = order;
@@ -1339,9 +1370,9 @@ void drone_vec_reset(DroneVec* v, uint64_t seed) {
     v->step_launches = 0;  // the reset kernel zeroes both done-count slots
     v->list_valid = false;
     v->many_k = 0;
-    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u};
     if (!upload_params(v) || !push_counters(v) || !peer_before_launch(v, &sig)) return;
-    HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream, &sig), return);
+    HIP_TRY(launch_reset(v->dv, v->cfg.task, v->stream, &sig), { peer_launch_failed(v); return; });
     if (v->host_buffers) device_to_host_outputs(v);
 }
 
@@ -1352,7 +1383,7 @@ bool step_send_impl(DroneVec* v) {
 #endif
     if (v->host_buffers && !host_to_device_actions(v)) return false;
     HOST_STAMP(kActionsIn);
-    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u};
     if (!peer_before_launch(v, &sig)) return false;
     const bool copy_out = v->host_buffers && v->zero_copy && v->threaded && v->h_flag;  // (without the completion flag the plain wait + whole copy is used)
     if (copy_out) {
@@ -1360,7 +1391,7 @@ bool step_send_impl(DroneVec* v) {
         sig.wg_done_value = ++v->wg_seq;
     }
     SweepTune::Pair* timing = v->tune ? tune_before_step(v) : nullptr;  // an HBM-bound handle still measuring its sweep order (may set dv.order for this launch)
-    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream, &sig), return false);
+    HIP_TRY(launch_step(v->dv, v->cfg.task, v->gstep, v->step_launches & 1u, v->stream, &sig), { peer_launch_failed(v); return false; });
     HOST_STAMP(kLaunched);
     if (timing && hipEventRecord(timing->e1, v->stream) != hipSuccess) {  // (v->tune is still there: a pair is only handed out while measuring)
         (void)hipGetLastError();
@@ -1407,9 +1438,9 @@ void drone_vec_rollout(DroneVec* v, int horizon) {
     Entry in(v);
     if (!in || !idle(v, "rollout")) return;
     if (horizon <= 0) { set_err("rollout: horizon must be positive, got %d", horizon); return; }
-    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
+    LaunchSig sig = {nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u};
     if (!peer_before_launch(v, &sig)) return;
-    HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream, &sig), return);
+    HIP_TRY(launch_rollout(v->dv, v->cfg.task, v->gstep, (uint32_t)horizon, v->stream, &sig), { peer_launch_failed(v); return; });
     v->gstep += (uint32_t)horizon;
     v->list_valid = false;  // the fused rollout builds no done-id list
     v->many_k = 0;
@@ -2087,6 +2118,8 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
     }
     if (g->counts[rank] != (size_t)v->n) { set_err("gather_init_peer: counts[rank] = %zu but this handle has %d envs", g->counts[rank], v->n); delete g; return -1; }
     g->own_obs = v->dv.obs; g->own_rew = v->dv.rew; g->own_term = v->dv.term; g->own_trunc = v->dv.trunc;
+    if (v->tune) { v->dv.order = v->tune->table; tune_free(v); }  // (DRONE_AUTOTUNE=1) no measuring under the exchange: the table's choice stands
+    g->own_order = v->dv.order;
     v->gather = g;  // from here on gather_destroy undoes whatever was done
     // the flag page: pinned + mapped so that stream memory operations can reach it (it owns its page: the rule of pin_caller_buffer)
     if (!already_pinned(shared_flags, kPage)) {
@@ -2102,11 +2135,13 @@ int drone_vec_gather_init_peer(DroneVec* v, const unsigned char* token, void* sh
     if (sw && *sw) g->stream_writes = atoi(sw) != 0;
     const char* ik = getenv("DRONE_PEER_INKERNEL");       // 0: the flag publications as one-wave launches of their own (round 4's form; A/B)
     if (ik && *ik) g->in_kernel = atoi(ik) != 0;
-    if (rank != root && g->in_kernel && g->gpu_waits && !g->stream_writes) {
-        HIP_TRY(hipMalloc((void**)&g->d_arrive, 64), { gather_destroy(v); return -1; });
-        HIP_TRY(hipMemsetAsync(g->d_arrive, 0, 64, v->stream), { gather_destroy(v); return -1; });
-    }
     if (g->gpu_waits) {
+        HIP_TRY(hipMalloc((void**)&g->d_arrive, kPeerBlockBytes), { gather_destroy(v); return -1; });
+        HIP_TRY(hipMemsetAsync(g->d_arrive, 0, kPeerBlockBytes, v->stream), { gather_destroy(v); return -1; });
+        if (v->dv.order & 12u) {  // the peer instantiations of the step kernel carry no load hints (a speed choice, never a result)
+            v->dv.order &= 3u;
+            write_variant(v, " peer=1");
+        }
         void* he = nullptr;
         HIP_TRY(hipHostMalloc(&he, 64, hipHostMallocMapped), { gather_destroy(v); return -1; });
         g->h_err = static_cast<uint32_t*>(he);
@@ -2156,6 +2191,7 @@ int drone_vec_gather(DroneVec* v) {
     if (g->peer) {
         // Peer stores: the rows are already where they belong (the kernels wrote them there). A non-root rank publishes
         // "my launch #seq has landed" behind its kernel; the root's stream waits until every other rank has said so.
+        g->launched = false;
         if (!peer_check_err(g)) return -1;
         g->seq += 1u;
         if (g->rank != g->root) {

@@ -240,15 +240,22 @@ class PeerStoreGather:
                 self.trunc = torch.zeros(self.total, dtype=torch.uint8, device=dev)
                 # A job that is SIGKILLed between creating the page and unlinking it (below: once every rank has mapped it) leaves 4 KiB
                 # behind under a name that carries its pid: sweep what dead processes of this user left, then make a fresh name,
-                # created exclusively (never an existing file or a symlink someone planted under a guessable name), private to this user
+                # created exclusively (never an existing file or a symlink someone planted under a guessable name), private to this user.
+                # Only pages older than ten minutes go: with /dev/shm shared across PID namespaces (containers with host
+                # IPC) a LIVE job's pid may not exist here, and its page lives for the seconds between its creation and the barrier below.
+                import time
+
                 for stale in os.listdir("/dev/shm"):
                     if stale.startswith("drone_peer_flags_"):
+                        path = os.path.join("/dev/shm", stale)
                         try:
+                            if time.time() - os.stat(path).st_mtime < 600.0:
+                                continue
                             os.kill(int(stale.split("_")[3]), 0)
                         except ProcessLookupError:
                             with contextlib.suppress(OSError):
-                                os.unlink(os.path.join("/dev/shm", stale))
-                        except (ValueError, IndexError, PermissionError):
+                                os.unlink(path)
+                        except (ValueError, IndexError, PermissionError, OSError):
                             pass
                 name = f"/dev/shm/drone_peer_flags_{os.getpid()}_{secrets.token_hex(8)}"
                 fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_RDWR | getattr(os, "O_NOFOLLOW", 0), 0o600)
@@ -261,14 +268,28 @@ class PeerStoreGather:
         finally:
             # every rank reaches the broadcast, also when the root failed above: the others then see [None, None] and raise instead of hanging
             dist.broadcast_object_list(box, src=src, group=group)
+        failure = None
         try:
             if box[0] is None:
                 raise RuntimeError("PeerStoreGather: the root could not export its batch")
             self._flags = np.memmap(box[1], dtype=np.uint32, mode="r+", shape=(1024,))  # one shared page, page-aligned
             vec.gather_init_peer(box[0], self._flags, self.rank, self.world, root=self.root, counts=self.counts)
-            dist.barrier(group=group)  # every rank has mapped the page: its NAME can go now, the memory lives as long as the mappings
+        except Exception as exc:  # noqa: BLE001  (re-raised below, once every rank knows)
+            failure = exc
+        try:
+            # Every rank reaches this exchange whether or not it could map the page (a rank that raised above used to skip
+            # the barrier and leave the others in it until the process-group timeout); it doubles as the barrier — every rank has
+            # mapped the page, its NAME can go now, the memory lives as long as the mappings.
+            oks = [None] * self.world
+            dist.all_gather_object(oks, failure is None, group=group)
         finally:
             self._unlink()
+        if failure is not None or not all(oks):
+            if failure is None:
+                with contextlib.suppress(Exception):
+                    vec.gather_close()
+                failure = RuntimeError(f"PeerStoreGather: rank(s) {[r for r, ok in enumerate(oks) if not ok]} could not join the exchange")
+            raise failure
 
     def _unlink(self):
         import os

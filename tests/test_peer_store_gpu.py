@@ -362,3 +362,127 @@ def test_waits_queued_behind_a_dead_peers_timeout_return_at_once(hip, tmp_path):
     lines = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.split(" ", 1)[0] in ("QUEUED", "ERROR", "NOERROR", "ELAPSED"))
     assert "ERROR" in lines and "gave up" in lines["ERROR"], r.stdout
     assert float(lines["ELAPSED"]) < 12.0, f"queued waits spun their budgets one after the other: {r.stdout}"
+
+
+_WORKER_QUIET_ROOT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from drone_amd import binding
+rank, tokfile, flagfile, rollout = int(sys.argv[1]), sys.argv[2], sys.argv[3], int(sys.argv[4])
+n = 4096
+dev = torch.device("cuda:0")
+v = binding.DroneVec(n, seed=3, cfg=binding.default_config(0, env_offset=rank * n), device=dev)
+flags = np.memmap(flagfile, dtype=np.uint32, mode="r+", shape=(1024,))
+if rank == 0:
+    g = (torch.zeros((2 * n, 20), dtype=torch.float32, device=dev), torch.zeros(2 * n, dtype=torch.float32, device=dev),
+         torch.zeros(2 * n, dtype=torch.uint8, device=dev), torch.zeros(2 * n, dtype=torch.uint8, device=dev))
+    tok = v.gather_peer_export(*g)
+    with open(tokfile + ".tmp", "wb") as fh: fh.write(tok)
+    os.rename(tokfile + ".tmp", tokfile)
+else:
+    t0 = time.time()
+    while not os.path.exists(tokfile):
+        assert time.time() - t0 < 120
+        time.sleep(0.01)
+    tok = open(tokfile, "rb").read()
+v.gather_init_peer(tok, flags, rank, 2, root=0)
+v.reset(3); v.gather()
+torch.cuda.synchronize()
+if rank == 0:
+    # round 1 is in: the consumer takes its time over it and launches nothing more, so round 1 is never acknowledged
+    first = g[0].clone()
+    assert first[n:].abs().sum().item() > 0, "rank 1's reset rows never arrived"
+    t0 = time.time()
+    while not os.path.exists(tokfile + ".rank1_done"):
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    torch.cuda.synchronize()
+    print("ROWS_UNTOUCHED", bool(torch.equal(first, g[0])), flush=True)
+    time.sleep(0.2)
+else:
+    err = None
+    try:
+        for k in range(6):   # queued behind the acknowledgement that never comes: the first wait gives up after the budget ...
+            if rollout: v.rollout(rollout)
+            else: v.fill_random_actions(); v.step()
+            v.gather()
+        torch.cuda.synchronize()
+        v.step()
+    except RuntimeError as exc:
+        err = str(exc)
+    torch.cuda.synchronize()
+    print("RANK1_ERROR", err, flush=True)
+    open(tokfile + ".rank1_done", "w").close()
+    time.sleep(1.0)   # keep the mapping alive while the root compares
+"""
+
+
+@pytest.mark.parametrize("rollout", [0, 16])
+def test_launches_queued_behind_a_failed_wait_store_nothing(hip, tmp_path, rollout):
+    """ADVICE r4 / VERDICT r5 item 2: the launches a rank queued behind a timed-out acknowledgement wait used to run anyway and
+    overwrite the root's batch — which the root, merely slow, may still be reading. The wait now raises a stop word in HBM as
+    well (drone_kernels.h LaunchSig) and the PEER instantiations of the step / rollout / reset kernels — which only handles in
+    an exchange launch; every other handle's kernels are round 5's, instruction for instruction (tests/test_build_variants.py)
+    — store and publish nothing once it is raised: the root's whole batch is bit for bit what it was while rank 1's six queued
+    launches drain."""
+    script = tmp_path / "worker_quiet.py"
+    script.write_text(_WORKER_QUIET_ROOT.format(root=ROOT))
+    tokfile = str(tmp_path / "token")
+    flagfile = f"/dev/shm/drone_peer_flags_{os.getpid()}_quiet{rollout}"
+    with open(flagfile, "wb") as fh:
+        fh.write(b"\0" * 4096)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DRONE_PEER_TIMEOUT_MS="1500")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), tokfile, flagfile, str(rollout)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        os.unlink(flagfile)
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert "RANK1_ERROR" in outs[1][0] and "gave up" in outs[1][0], outs[1][0]
+    assert "ROWS_UNTOUCHED True" in outs[0][0], outs[0][0]
+
+
+def test_two_launches_without_a_gather_are_refused(hip, tmp_path):
+    """with the publications riding on the output-writing launches, reset(); step(); gather() would let the second
+    launch overwrite this rank's rows of the root's batch while the root may be consuming the round the first one announced
+    (its wait is already satisfied). The library now insists on one drone_vec_gather per launch while the exchange is active
+    — on every rank, the root included — and says so; after the gather the handle steps again."""
+    import torch
+
+    n = 2048
+    dev = torch.device("cuda:0")
+    v = hip.DroneVec(n, seed=5, task=0, device=dev)
+    g = (torch.zeros((n, 20), dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev),
+         torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
+    flagfile = f"/dev/shm/drone_peer_flags_{os.getpid()}_twice"
+    with open(flagfile, "wb") as fh:
+        fh.write(b"\0" * 4096)
+    try:
+        flags = np.memmap(flagfile, dtype=np.uint32, mode="r+", shape=(1024,))
+        tok = v.gather_peer_export(*g)
+        v.gather_init_peer(tok, flags, 0, 1, root=0)
+        v.reset(5)
+        v.fill_random_actions()
+        with pytest.raises(RuntimeError, match="drone_vec_gather must follow every"):
+            v.step()
+        v.clear_status()
+        v.gather()
+        v.step(); v.gather()
+        v.rollout(4)
+        with pytest.raises(RuntimeError, match="drone_vec_gather must follow every"):
+            v.rollout(4)
+        v.clear_status()
+        v.gather()
+        torch.cuda.synchronize()
+        assert "peer" not in v.variant[0] or v.variant[1]["mem"] == 0
+        v.gather_close()
+        v.step(); v.step()  # no exchange, no rule
+        torch.cuda.synchronize()
+    finally:
+        v.close()
+        os.unlink(flagfile)

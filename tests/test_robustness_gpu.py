@@ -233,11 +233,11 @@ def test_sweep_orders_are_bijective(oracle, hip, monkeypatch, order, n):
 
 
 def test_sweep_order_measured_on_the_handles_own_steps(hip, monkeypatch):
-    """Round 5: a handle whose step touches more than 400 MiB measures its sweep order ONLINE — from its 161st
-    step launch on the candidates 0 / 6 / 8 take turns in bursts of sixteen real steps, timed by HIP events read back lazily;
-    nothing extra is launched. Until the measurement is complete the footprint table's pick stands and the handle says nothing;
-    afterwards it names what it tried and runs the fastest. DRONE_AUTOTUNE=0 keeps the table for good; a forced order is not
-    second-guessed. A sweep order only permutes which workgroup takes which chunk: all three handles walk the same trajectory,
+    """DRONE_AUTOTUNE=1 (round 5's default, opt-in since round 6: it re-derived the footprint table in 12 of 12 logged cases): a
+    handle whose step touches more than 400 MiB measures its sweep order ONLINE — from its 161st step launch on the candidates
+    0 / 6 / 8 take turns in bursts of sixteen real steps, timed by HIP events read back lazily; nothing extra is launched. Until
+    the measurement is complete the footprint table's pick stands and the handle says nothing; afterwards it names what it tried
+    and runs the fastest. Without the variable the table stands for good; a forced order is not second-guessed. A sweep order only permutes which workgroup takes which chunk: all three handles walk the same trajectory,
     outputs and done lists included — also THROUGH the steps in which the order changes every sixteen launches."""
     import zlib
 
@@ -258,6 +258,7 @@ def test_sweep_order_measured_on_the_handles_own_steps(hip, monkeypatch):
         return out
 
     at = (150, 170, 200, 230, 320)  # before the measurement, inside three different bursts, after it
+    monkeypatch.setenv("DRONE_AUTOTUNE", "1")
     h = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
     h.reset(seed)
     assert "autotuned" not in h.variant[0]
@@ -272,20 +273,20 @@ def test_sweep_order_measured_on_the_handles_own_steps(hip, monkeypatch):
     h.reset(seed)  # a reset later on changes nothing: measured once per handle
     assert h.variant[0] == text
     h.close()
-    monkeypatch.setenv("DRONE_AUTOTUNE", "0")
+    monkeypatch.delenv("DRONE_AUTOTUNE")  # the default: the table
     h0 = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
     h0.reset(seed)
     b = run(h0, 320, at)
     assert "autotuned" not in h0.variant[0] and h0.variant[1]["order"] == var["table"]
     h0.close()
-    monkeypatch.delenv("DRONE_AUTOTUNE")
+    monkeypatch.setenv("DRONE_AUTOTUNE", "1")  # ... and a forced order is not second-guessed even when asked to measure
     monkeypatch.setenv("DRONE_SWEEP_ORDER", "2")
     h2 = hip.DroneVec(n, seed=seed, task=0, device="cuda:0", horizon=12, compact_done=1)
     h2.reset(seed)
     c = run(h2, 320, at)
     assert "autotuned" not in h2.variant[0] and h2.variant[1]["order"] == 2
     h2.close()
-    for other, name in ((b, "DRONE_AUTOTUNE=0"), (c, "forced order 2")):
+    for other, name in ((b, "the table (default)"), (c, "forced order 2")):
         for t in at:
             assert other[t][0] == a[t][0] and np.array_equal(other[t][1], a[t][1]), f"{name}: after {t} steps the trajectory differs from the measuring handle's"
 

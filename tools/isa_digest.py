@@ -32,7 +32,17 @@ def canonical(names):
             elif ch == "(" and depth == 0:
                 cut = i
                 break
-        res[m] = d[:cut]
+        d = d[:cut]
+        # round 6: the reset / step / rollout kernels gained a trailing template argument, PEER (the stop word of the peer-store
+        # exchange). PEER = false IS the kernel of the rounds before — keyed as it was, so that its ISA can be held to the measured
+        # one; PEER = true is a kernel of its own, keyed `..._peer_kernel<...>`
+        arity = {"drone_reset_kernel": 1, "drone_rollout_kernel": 2, "drone_step_kernel": 4}
+        fam = d.split("<")[0]
+        if fam in arity and d.endswith(">"):
+            args = [a.strip() for a in d[len(fam) + 1:-1].split(",")]
+            if len(args) == arity[fam] + 1:
+                d = (fam if args[-1] == "false" else fam.replace("_kernel", "_peer_kernel")) + "<" + ", ".join(args[:-1]) + ">"
+        res[m] = d
     return res
 
 
