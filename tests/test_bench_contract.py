@@ -121,7 +121,26 @@ def check_two_rank_line(r, optional_ok=True):
     ch = d["records"]["c_host_mp"]  # the plain-C multi-process host, run as a child with a timeout after the line was complete
     assert ch["per_step"]["gpus"] == 2 and ch["per_step"]["envs"] == 131073 and ch["per_step"]["env_steps_per_s"] > 0
     assert ch["rollout"]["horizon"] == 128 and ch["rollout"]["env_steps_per_s"] > 0
+    check_preflight(d, 2)
     return d
+
+
+PREFLIGHT_ITEMS = {"devices", "peer_access", "flag_page_host", "ipc_store_roundtrip", "nccl_allgather_1mib", "cabi_rccl_gather"}
+
+
+def check_preflight(d, world, failed=()):
+    """the ~10 s preflight child job between the core records and the optional ones, in rank 0's line. On the
+    1-GPU box the ranks share the device over gloo: the items that need one device per rank say so, the rest must pass — the
+    flag page seen by every rank, and rows stored through an IPC mapping of the root's batch arriving bit for bit."""
+    pf = d["preflight"]
+    assert pf["status"].startswith("ok"), pf
+    assert PREFLIGHT_ITEMS <= set(pf), PREFLIGHT_ITEMS - set(pf)
+    assert pf["devices"]["ranks"] == world and pf["devices"]["per_rank"] == [1] * world and pf["devices"]["backend"] == "gloo"
+    for item in ("peer_access", "nccl_allgather_1mib", "cabi_rccl_gather"):
+        assert pf[item].startswith("n/a:") and "1 device" in pf[item], (item, pf[item])
+    for item in ("flag_page_host", "ipc_store_roundtrip"):
+        assert pf[item].startswith("failed" if item in failed else "ok"), (item, pf[item])
+    assert float(pf["status"].split("(")[1].split()[0]) < 30.0, pf["status"]  # "ok (9 s)": what it adds to the job
 
 
 @pytest.mark.gpu
@@ -187,6 +206,24 @@ def test_two_rank_launch_reports_the_metrics_configuration(hip):
 
 
 @pytest.mark.gpu
+def test_a_failed_preflight_item_skips_the_records_that_rest_on_it(hip):
+    """an item the preflight finds broken (here injected on the last rank) turns the optional records that rest
+    on it into "skipped: preflight <item>" — by name, on every rank alike, at once — while the other optional records run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DRONE_BENCH_FAULT="preflight:ipc_store_roundtrip")
+    env = {k: val for k, val in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--total-envs", "131073"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    check_preflight(d, 2, failed=("ipc_store_roundtrip",))
+    assert "injected" in d["preflight"]["ipc_store_roundtrip"] and "rank 1" in d["preflight"]["ipc_store_roundtrip"]
+    for name in ("gather_peer_store", "rollout_gather_peer_store"):
+        assert d["records"][name]["skipped"].startswith("preflight ipc_store_roundtrip"), d["records"][name]
+    assert d["optional"].startswith("ok") and d["records"]["gather_root_step"]["env_steps_per_s"] > 0 and d["value"] > 0
+    assert "gather_peer_store" not in d["secondary_values"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fault,how,pg_timeout", [("hang:gather_root_step", "timed out", "600"), ("die:gather_peer_store", "failed", "25")])
 def test_a_rank_lost_in_an_optional_record_cannot_cost_the_line(hip, fault, how, pg_timeout):
     """one rank of the OPTIONAL job hangs (never enters the record's collectives) or dies mid-record.
@@ -235,6 +272,8 @@ def test_eight_ranks_oversubscribed_at_the_metrics_shape(hip):
     assert n1["envs"] == 1 << 20 and n1["per_step"]["env_steps_per_s"] > 0 and n1["rollout"]["env_steps_per_s"] > 0
     assert CORE <= set(d["records"])
     assert "timed out" not in d["optional"] and d["optional"].startswith("ok"), d["optional"]
+    pf = d["preflight"]  # eight ranks on the one GPU: the IPC store + flag round trip with seven peers, bit for bit
+    assert pf["status"].startswith("ok") and pf["ipc_store_roundtrip"].startswith("ok") and pf["flag_page_host"].startswith("ok") and pf["devices"]["ranks"] == 8, pf
     assert OPTIONAL <= set(d["records"]), OPTIONAL - set(d["records"])
     for name in CORE | OPTIONAL:
         if name != "n1_same_box":
