@@ -4,7 +4,7 @@ from, whose fused-rollout kernel had one argument fewer). Every round-5 profile 
 of the libdrone_hip.so that ran on the GPU box) and its kernels by demangled and mangled name; here, on the CPU:
   * the kernel rows of kernel_stats.csv and of summary.json are the same kernels;
   * every mangled name exists in the ISA listing of the CURRENT sources (a kernel renamed or re-templated after the
-    profile was taken makes the profile stale: re-run tools/r05_profiles.sh + tools/collect_round.py r05);
+    profile was taken makes the profile stale: re-run tools/round_profiles.sh <round> + tools/collect_round.py <round>);
   * all directories, traffic_latest.json and rollout_valu.json come from ONE build, taken from a clean tree;
   * the roofline fraction of the committed bench line is reproduced from the profile: algorithmic bytes x envs /
     rocprofv3's average kernel time / 8 TB/s."""
@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND = "r05"
 DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", ROUND + "_*")) if os.path.isfile(os.path.join(d, "summary.json")))
 
-pytestmark = pytest.mark.skipif(not DIRS, reason="no round-5 profiles committed yet (tools/r05_profiles.sh on the GPU box, tools/collect_round.py r05 here)")
+pytestmark = pytest.mark.skipif(not DIRS, reason="no round-5 profiles committed yet (tools/round_profiles.sh on the GPU box, tools/collect_round.py here)")
 
 
 @pytest.fixture(scope="module")

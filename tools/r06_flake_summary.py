@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""gpurun_out/r06_flake/<tag>/{box.txt,runs.jsonl,...} (tools/r06_flake.sh, one tag per gpurun call = per box) ->
+profiles/r06_flake/summary.json + a table on stdout: failures / runs per (build, workload) cell, per box, the whole-suite
+runs, the fault texts seen, and an upper bound on the failure rate of each build's eight-process runs (exact one-sided 95 %
+Clopper-Pearson bound; with zero failures in n runs that is 1 - 0.05^(1/n), the "rule of three" 3/n).
+
+    python3 tools/r06_flake_summary.py            # writes profiles/r06_flake/summary.json, copies every failure's text beside it
+"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r06_flake")
+DST = os.path.join(ROOT, "profiles", "r06_flake")
+BUILDS = {"A": "as shipped by round 5 (kernarg preload, -DDRONE_EARLY_ARGS=2)", "B": "-DDRONE_EARLY_ARGS=0 without -mllvm -amdgpu-kernarg-preload-count=12",
+          "C": "A + profiles/r05_ab/stop_word_withdrawn.patch (round 5's stop word in every instantiation)",
+          "D": "round 6: pruned source, stop word as PEER instantiations only (what ships)", "E": "D without kernarg preloading"}
+
+
+def upper95(fails, n):
+    """one-sided 95 % Clopper-Pearson upper bound on a failure probability, by bisection on the binomial tail"""
+    if n == 0:
+        return None
+    if fails >= n:
+        return 1.0
+    from math import comb
+
+    def cdf(p):  # P[X <= fails]
+        return sum(comb(n, k) * p ** k * (1 - p) ** (n - k) for k in range(fails + 1))
+
+    lo, hi = 0.0, 1.0
+    for _ in range(60):
+        mid = (lo + hi) / 2
+        lo, hi = (mid, hi) if cdf(mid) > 0.05 else (lo, mid)
+    return round(hi, 4)
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    runs, boxes = [], {}
+    for tag_dir in sorted(glob.glob(os.path.join(SRC, "*"))):
+        tag = os.path.basename(tag_dir)
+        p = os.path.join(tag_dir, "runs.jsonl")
+        if not os.path.isfile(p):
+            continue
+        for line in open(p):
+            line = line.strip()
+            if line:
+                try:
+                    runs.append(json.loads(line))
+                except ValueError:
+                    print("unparseable line in", p, ":", line[:120], file=sys.stderr)
+        box = open(os.path.join(tag_dir, "box.txt")).read() if os.path.isfile(os.path.join(tag_dir, "box.txt")) else ""
+        boxes[tag] = {"box_txt": box.strip().splitlines()[:14]}
+        for f in sorted(glob.glob(os.path.join(tag_dir, "fail_*.txt")) + glob.glob(os.path.join(tag_dir, "soft_*.txt")) + glob.glob(os.path.join(tag_dir, "*.dmesg"))):
+            shutil.copy(f, os.path.join(DST, f"{tag}_{os.path.basename(f)}"))
+        for f in sorted(glob.glob(os.path.join(tag_dir, "suite_*.txt"))):
+            text = open(f, errors="replace").read()
+            if " failed" in text.splitlines()[-1] if text.strip() else True:  # a suite with failures (or no summary line): keep its whole output
+                shutil.copy(f, os.path.join(DST, f"{tag}_{os.path.basename(f)}"))
+            else:
+                open(os.path.join(DST, f"{tag}_{os.path.basename(f)}"), "w").write("\n".join(text.splitlines()[-3:]) + "\n")
+    cells, suites, per_build, faults = {}, {}, {}, {}
+    for r in runs:
+        failed = r["rc"] != 0
+        if r["workload"] == "suite":
+            s = suites.setdefault(r["build"], {"runs": 0, "failed": 0, "detail": []})
+            s["runs"] += 1
+            s["failed"] += failed
+            s["detail"].append({"tag": r["tag"], "rc": r["rc"], "seconds": r["seconds"], "summary": r.get("summary", "")})
+        else:
+            c = cells.setdefault(r["build"], {}).setdefault(r["workload"], {"runs": 0, "failed": 0, "soft": 0, "seconds": 0, "by_box": {}})
+            c["runs"] += 1
+            c["failed"] += failed
+            c["seconds"] += r["seconds"]
+            soft = (not failed) and r["workload"] == "bench8" and not str(r.get("optional", "")).startswith("ok")
+            c["soft"] += soft
+            b = c["by_box"].setdefault(r["tag"], [0, 0])
+            b[0] += failed
+            b[1] += 1
+            t = per_build.setdefault(r["build"], [0, 0])
+            t[0] += failed
+            t[1] += 1
+        for f in r.get("faults", []):
+            if failed or "HSA" in f or "fault" in f or "ILLEGAL" in f:
+                faults.setdefault(r["build"], {}).setdefault(f.rsplit(" x", 1)[0], []).append(f"{r['tag']}/{r['workload']}/{r['rep']}")
+    for b in cells.values():
+        for c in b.values():
+            c["avg_seconds"] = round(c.pop("seconds") / max(1, c["runs"]), 1)
+    out = {"builds": {k: v for k, v in BUILDS.items() if k in per_build or k in suites}, "boxes": boxes,
+           "eight_process_cells": cells, "whole_gpu_suite": suites,
+           "eight_process_totals": {b: {"failed": f, "runs": n, "failure_rate_upper_bound_95": upper95(f, n)} for b, (f, n) in sorted(per_build.items())},
+           "fault_texts": faults,
+           "note": "every repetition is a fresh child process (a pytest session of its own, or bench.py --gpus 8 itself); eight processes share the one GPU of the "
+                   "box; `soft` = the bench line arrived with rc 0 but an optional exchange record lost its budget"}
+    json.dump(out, open(os.path.join(DST, "summary.json"), "w"), indent=1, sort_keys=True)
+    print(f"{len(runs)} runs on {len(boxes)} box(es)")
+    wl = sorted({w for b in cells.values() for w in b})
+    print("build  " + "  ".join(f"{w:>10}" for w in wl) + "   |  8-proc total   <=95%   | suites")
+    for b in sorted(set(cells) | set(suites)):
+        row = "  ".join(f"{cells.get(b, {}).get(w, {}).get('failed', 0)}/{cells.get(b, {}).get(w, {}).get('runs', 0):<3}".rjust(10) for w in wl)
+        f, n = per_build.get(b, (0, 0))
+        s = suites.get(b, {"failed": 0, "runs": 0})
+        print(f"{b:<6} {row}   |  {f}/{n:<4}  {str(upper95(f, n)):>8}   | {s['failed']}/{s['runs']} failed")
+    for b, d in faults.items():
+        for text, where in d.items():
+            print(f"  build {b}: '{text}' in {len(where)} run(s): {where[:6]}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,10 +1,12 @@
 #!/bin/bash
-# GPU box: the round-5 evidence set, ALL from the one libdrone_hip.so that travelled with this snapshot (its sha256 and
-# the git revision it was built from are recorded in gpurun_out/r05_prof/build.json and copied into every summary by
-# tools/collect_round.py r05, which turns gpurun_out/r05_prof/ into profiles/r05_*).
+# GPU box: a round's evidence set, ALL from the one libdrone_hip.so that travelled with this snapshot (its sha256 and
+# the git revision it was built from are recorded in gpurun_out/<round>_prof/build.json and copied into every summary by
+# tools/collect_round.py <round>, which turns gpurun_out/<round>_prof/ into profiles/<round>_*).
+#   usage: tools/round_profiles.sh r06
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"
-P=r05_prof
+ROUND="${1:?round tag, e.g. r06}"
+P=${ROUND}_prof
 mkdir -p gpurun_out/$P
 python3 - <<'PY' > gpurun_out/$P/build.json
 import hashlib, json, os
@@ -36,17 +38,16 @@ done
 bash tools/pmc_pass.sh $P/sq_step_65536 "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU" --steps 200 --warmup 20 --envs-per-gpu 65536 > /dev/null 2>&1
 # where the rollout's waves run and how they share their SIMD; the shader clock held (diagnostic builds of the same sources)
 python3 tools/wg_census.py --envs 65536 131072 262144 1048576 --blocks 256 > gpurun_out/$P/wg_census.txt 2> gpurun_out/$P/wg_census.err
-python3 tools/wg_census.py --envs 131072 262144 --blocks 256 --extra=-DDRONE_PRIO_ROTATE=0 > gpurun_out/$P/wg_census_oldest_first.txt 2>> gpurun_out/$P/wg_census.err
 python3 tools/rollout_clock.py --envs 65536 131072 262144 1048576 --valu-per-wave-step 414 > gpurun_out/$P/rollout_clock.txt 2> gpurun_out/$P/rollout_clock.err
 # collect on the box too, so that the bench lines below read THIS build's traffic_latest.json / rollout_valu.json
 # (the same collector runs again on the merged-back raw files at home and must produce the same profiles/)
-python3 tools/collect_round.py r05 > gpurun_out/$P/collect_on_box.log 2>&1
+python3 tools/collect_round.py $ROUND > gpurun_out/$P/collect_on_box.log 2>&1
 python bench.py > gpurun_out/$P/bench_default.json 2> gpurun_out/$P/bench_default.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/$P/bench_driver_window.json 2> gpurun_out/$P/bench_driver_window.err
 python bench.py --force-dist --steps 200 --warmup 20 > gpurun_out/$P/bench_force_dist_one_rank.json 2> gpurun_out/$P/bench_force_dist.err
-for d in step_hover_4194304 step_hover step_hover_65536 step_hover_131072 step_waypoint_262144 step_many_65536 rollout_hover rollout_hover_131072 rollout_hover_262144; do echo "== $d"; python3 - "$d" <<'PY'
+for d in step_hover_4194304 step_hover step_hover_65536 step_hover_131072 step_waypoint_262144 step_many_65536 rollout_hover rollout_hover_131072 rollout_hover_262144; do echo "== $d"; python3 - "$d" "$P" <<'PY'
 import json,sys
-s=json.load(open(f"gpurun_out/r05_prof/{sys.argv[1]}/summary.json"))
+s=json.load(open(f"gpurun_out/{sys.argv[2]}/{sys.argv[1]}/summary.json"))
 for k,v in s["kernel_trace_avg_us"].items():
     if "step_kernel" in k or "rollout" in k or "many" in k: print(k[:90], v)
 for k,v in s["traffic"].items():
