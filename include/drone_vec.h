@@ -335,9 +335,16 @@ void drone_vec_gather_close(DroneVec* v);
  * stale round. drone_vec_gather_close gives the handle its own output buffers back and forgets the export (export again
  * before another drone_vec_gather_init_peer). A dead peer: every wait gives up after DRONE_PEER_TIMEOUT_MS (default
  * 10 000; clamped to 1 ... 600 000, anything else is the default) — a stream-side wait raises a flag that fails the next
- * call on the handle and makes every wait already queued behind it return at once (the launches queued behind it still
- * run and store their rows: after such an error the root's batch is not to be trusted); DRONE_PEER_HOST_WAIT=1 moves the whole
- * handshake to the host (the stream is drained, the host polls / stores), where the timeout is an immediate error. */
+ * call on the handle, makes every wait already queued behind it return at once, and (round 6) raises a stop word in HBM:
+ * the reset / step / rollout launches already queued behind it store nothing and publish nothing, so the root's batch stays
+ * what it was while they drain (handles in an exchange launch instantiations of their own for this; every other handle's
+ * kernels do not know the word); DRONE_PEER_HOST_WAIT=1 moves the whole handshake to the host (the stream is drained, the
+ * host polls / stores), where the timeout is an immediate error.
+ * ONE drone_vec_gather per output-writing launch (round 6): a second reset / step / rollout before the gather fails with a
+ * message — its wait would already be satisfied and it would overwrite rows the root may be consuming.
+ * The exported buffers must be plain device allocations (drone_device_malloc, hipMalloc, torch's default allocator): a
+ * virtual-memory mapping (hipMemCreate / hipMemMap, torch's expandable_segments) has no IPC handle, and
+ * drone_vec_gather_peer_export says so. */
 #define DRONE_PEER_TOKEN_BYTES 288
 int drone_vec_gather_peer_export(DroneVec* v, float* all_observations, float* all_rewards,
                                  unsigned char* all_terminals, unsigned char* all_truncations, unsigned char* token);
