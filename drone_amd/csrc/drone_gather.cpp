@@ -251,7 +251,7 @@ extern "C" {
 
 // ---- host-boundary all-gather (RCCL) ----
 int drone_gather_unique_id(unsigned char* id) {
-    g_err[0] = 0;
+    err_text()[0] = 0;
     if (!id) { set_err("gather_unique_id: NULL buffer"); return -1; }
     Rccl* R = rccl();
     if (!R) return -1;

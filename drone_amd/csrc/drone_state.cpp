@@ -265,7 +265,7 @@ int drone_vec_done_list_at(DroneVec* v, int k, uint32_t* ids, int cap) {
 }
 
 void* drone_device_malloc(int device, size_t bytes) {
-    g_err[0] = 0;
+    err_text()[0] = 0;
     DeviceRestore restore;
     void* p = nullptr;
     HIP_TRY(hipSetDevice(device), return nullptr);

@@ -16,12 +16,13 @@
 
 DRONE_IMPL_NS {
 
-thread_local char g_err[512] = "";
+static thread_local char g_err_storage[kErrBytes] = "";
+char* err_text() { return g_err_storage; }
 
 void set_err(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    vsnprintf(g_err_storage, sizeof(g_err_storage), fmt, ap);
     va_end(ap);
 }
 
@@ -119,7 +120,7 @@ using namespace drone_impl;
 
 extern "C" {
 
-const char* drone_last_error(void) { return g_err; }
+const char* drone_last_error(void) { return err_text(); }
 
 void drone_config_default(DroneConfig* c, int task) {
     memset(c, 0, sizeof(*c));
@@ -210,7 +211,7 @@ int drone_obs_dim(int task) { return (task == DRONE_TASK_SWARM || task == DRONE_
 
 DroneVec* drone_vec_init(float* observations, float* actions, float* rewards, unsigned char* terminals,
                          unsigned char* truncations, int num_envs, uint64_t seed, const DroneConfig* cfg) {
-    g_err[0] = 0;
+    err_text()[0] = 0;
     if (!validate(cfg, num_envs)) return nullptr;
     // all five NULL on a device-buffer handle: the library allocates them in HBM (drone_vec_buffers hands them out)
     const bool lib_buffers = cfg->buffer_kind == DRONE_BUFFERS_DEVICE && !observations && !actions && !rewards && !terminals && !truncations;

@@ -176,7 +176,12 @@ struct SweepTune {
 #define DRONE_IMPL_NS namespace drone_impl __attribute__((visibility("hidden")))
 DRONE_IMPL_NS {
 
-extern thread_local char g_err[512];
+// the calling thread's error text (512 bytes; drone_last_error). A function, not an `extern thread_local`: a hidden-visibility
+// thread_local referenced from another unit makes the compiler call its (non-existent, weak) TLS init function through a
+// PC-relative address that is never null in a shared object — the first build of the split crashed in every entry point
+// outside drone_vec.cpp that way.
+constexpr size_t kErrBytes = 512;
+char* err_text();
 void set_err(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 #define HIP_TRY(expr, onfail)                                                        \
@@ -209,7 +214,7 @@ struct Entry {
     int prev = -1;
     bool ok = false;
     explicit Entry(const DroneVec* cv) : v(const_cast<DroneVec*>(cv)) {
-        g_err[0] = 0;
+        err_text()[0] = 0;
         if (!v) { set_err("handle is NULL"); return; }
         if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
         if (prev != v->device) {
@@ -219,9 +224,10 @@ struct Entry {
         ok = true;
     }
     ~Entry() {
-        if (v && g_err[0] && v->status == 0) {
+        const char* err = v ? err_text() : nullptr;
+        if (v && err[0] && v->status == 0) {
             v->status = 1;
-            snprintf(v->status_msg, sizeof(v->status_msg), "%s", g_err);
+            snprintf(v->status_msg, sizeof(v->status_msg), "%s", err);
         }
         if (v && prev >= 0 && prev != v->device) (void)hipSetDevice(prev);
     }

@@ -110,3 +110,20 @@ def test_every_entry_point_is_named_in_the_integration_guide():
     declared = set(re.findall(r"\b(drone_[a-z_0-9]+)\s*\(", header))
     guide = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert {s for s in declared if s not in guide} == set()
+
+
+def test_no_call_through_an_unresolved_weak_symbol():
+    """Round 6: the first build of the split host code crashed in every entry point outside drone_vec.cpp — a hidden-visibility
+    `extern thread_local` made the compiler call the variable's (non-existent, weak) TLS init function, and in a shared object the
+    PC-relative address of an undefined weak symbol is the load base, never null: `call 0`. Nothing on the CPU suite executes
+    those paths with a live handle, so the disassembly is checked instead: no call or jump to address 0 anywhere in the library."""
+    import shutil
+    import subprocess
+
+    objdump = shutil.which("objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(ROOT, "drone_amd", "libdrone_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    out = subprocess.run([objdump, "-d", "--no-show-raw-insn", lib], capture_output=True, text=True, check=True).stdout
+    bad = [l for l in out.splitlines() if re.search(r"\b(call|jmp)\s+0x?0\b", l) or re.search(r"\b(call|jmp)\s+0 <", l)]
+    assert not bad, bad[:5]
