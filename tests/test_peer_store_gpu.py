@@ -5,6 +5,7 @@ output stores land in the root's HBM directly; `drone_vec_gather` is only a hand
 the same; what an 8-GPU node adds is that the stores cross xGMI): 2 and 3 processes, ragged shards, root first and last,
 20- and 24-float rows, per-step and fused launches — the root's batch after EVERY launch must be what one oracle run
 over all envs produces, bit for bit. Same pattern as tests/test_gather_multirank_gpu.py, without the RCCL test double."""
+import json
 import os
 import subprocess
 import sys
@@ -520,3 +521,14 @@ def test_export_of_a_virtual_memory_allocation_names_the_way_out(hip, tmp_path):
         pytest.skip("this torch build's allocator hands out plain allocations even with expandable_segments:True: the export works")
     line = next(l for l in r.stdout.splitlines() if l.startswith("ERROR"))
     assert "drone_device_malloc" in line and "hipIpcGetMemHandle" in line and "virtual-memory" in line, line
+
+
+@pytest.mark.parametrize("world,rollout", [(2, 0), (3, 16)])
+def test_many_rounds_per_process_start_every_batch_checked(hip, world, rollout):
+    """tests/peer_stress.py (round 6): 1 500 handshake rounds between `world` processes, the root dawdling at random, every
+    round's batch compared with what each rank computes in a twin handle — the dense form of the cases above, which spend
+    their seconds importing torch. tools/r06_flake.sh runs it by the thousand rounds per library variant."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "peer_stress.py"), "--world", str(world), "--rounds", "1500", "--rollout", str(rollout), "--seed", "7"],
+                       capture_output=True, text=True, timeout=400)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert r.returncode == 0 and line["mismatches"] == 0 and line["ranks_rc"] == [0] * world, (line, r.stderr[-2000:])

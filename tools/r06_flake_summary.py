@@ -9,6 +9,7 @@ Clopper-Pearson bound; with zero failures in n runs that is 1 - 0.05^(1/n), the 
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -75,6 +76,14 @@ def main():
             c = cells.setdefault(r["build"], {}).setdefault(r["workload"], {"runs": 0, "failed": 0, "soft": 0, "seconds": 0, "by_box": {}})
             c["runs"] += 1
             c["failed"] += failed
+            m = re.search(r"(?:(\d+) failed, )?(\d+) passed", str(r.get("summary", "")))
+            if m:  # a pytest session of several cases (peer_small / peer_file): cases counted as well as sessions
+                c["cases_failed"] = c.get("cases_failed", 0) + int(m.group(1) or 0)
+                c["cases"] = c.get("cases", 0) + int(m.group(1) or 0) + int(m.group(2))
+            if r.get("mismatches"):
+                c["torn_batches"] = c.get("torn_batches", 0) + 1
+            if r["workload"] == "peer_stress":
+                c["handshake_rounds"] = c.get("handshake_rounds", 0) + 3000
             c["seconds"] += r["seconds"]
             soft = (not failed) and r["workload"] == "bench8" and not str(r.get("optional", "")).startswith("ok")
             c["soft"] += soft
@@ -90,21 +99,29 @@ def main():
     for b in cells.values():
         for c in b.values():
             c["avg_seconds"] = round(c.pop("seconds") / max(1, c["runs"]), 1)
-    out = {"builds": {k: v for k, v in BUILDS.items() if k in per_build or k in suites}, "boxes": boxes,
+    def describe(b):
+        lib, _, env = b.partition("+")
+        return BUILDS.get(lib, lib) + (f"; run with {env}" if env else "")
+
+    out = {"builds": {b: describe(b) for b in sorted(set(per_build) | set(suites))}, "boxes": boxes,
            "eight_process_cells": cells, "whole_gpu_suite": suites,
-           "eight_process_totals": {b: {"failed": f, "runs": n, "failure_rate_upper_bound_95": upper95(f, n)} for b, (f, n) in sorted(per_build.items())},
+           "totals_over_cells": {b: {"failed": f, "runs": n, "failure_rate_upper_bound_95": upper95(f, n)} for b, (f, n) in sorted(per_build.items())},
            "fault_texts": faults,
            "note": "every repetition is a fresh child process (a pytest session of its own, or bench.py --gpus 8 itself); eight processes share the one GPU of the "
                    "box; `soft` = the bench line arrived with rc 0 but an optional exchange record lost its budget"}
     json.dump(out, open(os.path.join(DST, "summary.json"), "w"), indent=1, sort_keys=True)
     print(f"{len(runs)} runs on {len(boxes)} box(es)")
     wl = sorted({w for b in cells.values() for w in b})
-    print("build  " + "  ".join(f"{w:>10}" for w in wl) + "   |  8-proc total   <=95%   | suites")
+    print(f"{'build':<28} " + "  ".join(f"{w:>11}" for w in wl) + "   |  all cells   <=95%   | suites")
     for b in sorted(set(cells) | set(suites)):
-        row = "  ".join(f"{cells.get(b, {}).get(w, {}).get('failed', 0)}/{cells.get(b, {}).get(w, {}).get('runs', 0):<3}".rjust(10) for w in wl)
+        row = "  ".join(f"{cells.get(b, {}).get(w, {}).get('failed', 0)}/{cells.get(b, {}).get(w, {}).get('runs', 0):<3}".rjust(11) for w in wl)
         f, n = per_build.get(b, (0, 0))
         s = suites.get(b, {"failed": 0, "runs": 0})
-        print(f"{b:<6} {row}   |  {f}/{n:<4}  {str(upper95(f, n)):>8}   | {s['failed']}/{s['runs']} failed")
+        print(f"{b:<28} {row}   |  {f}/{n:<4}  {str(upper95(f, n)):>8}   | {s['failed']}/{s['runs']} failed")
+    for b in sorted(cells):
+        for w, c in sorted(cells[b].items()):
+            if "cases" in c or "torn_batches" in c or "handshake_rounds" in c:
+                print(f"  {b} / {w}: " + ", ".join(f"{k} {c[k]}" for k in ("cases_failed", "cases", "torn_batches", "handshake_rounds") if k in c))
     for b, d in faults.items():
         for text, where in d.items():
             print(f"  build {b}: '{text}' in {len(where)} run(s): {where[:6]}")
