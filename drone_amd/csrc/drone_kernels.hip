@@ -64,8 +64,8 @@ constexpr int kStepMinWaves = 5;  // __launch_bounds__ 2nd argument of the per-s
 #define DRONE_STAMP(k) do {} while (0)
 #endif
 
-#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count, Makefile PRELOAD); 0: wherever the compiler sinks their scalar loads (the build without kernarg preloading: make PRELOAD= EXTRA=-DDRONE_EARLY_ARGS=0). Round 4; the two forms in between (one scalar batch; the first loads issued by hand) are profiles/r06_pruned/
-#define DRONE_EARLY_ARGS 2
+#ifndef DRONE_EARLY_ARGS  // the words the per-step kernel's state-load addresses depend on — 0 (shipped since round 6): wherever the compiler sinks their scalar loads; 2: preloaded into SGPRs with the wave (leading scalar kernel arguments + -amdgpu-kernarg-preload-count: Makefile PRELOAD, where the reason for the default is). Round 4; the two forms in between (one scalar batch; the first loads issued by hand) are in profiles/r06_pruned/
+#define DRONE_EARLY_ARGS 0
 #endif
 #if DRONE_EARLY_ARGS != 0 && DRONE_EARLY_ARGS != 2
 #error "DRONE_EARLY_ARGS is 0 or 2"
@@ -349,9 +349,9 @@ __device__ __forceinline__ uint32_t my_chunk(uint32_t order, uint32_t gstep, uin
 // per-step kernel (SPEC.md §5): configs 1–4
 // =====================================================================
 // The leading scalar arguments repeat the words of `a` that the state-load addresses depend on. Built with
-// -mllvm -amdgpu-kernarg-preload-count (Makefile) they arrive in SGPRs with the wave — no scalar load, no wait — so the
-// state loads go out a scalar-memory round trip earlier (DRONE_EARLY_ARGS=2; firmware without kernarg preloading runs the
-// compatibility prologue the compiler emits, which loads them the old way).
+// -mllvm -amdgpu-kernarg-preload-count and -DDRONE_EARLY_ARGS=2 (Makefile PRELOAD; not the shipped build) they arrive in SGPRs
+// with the wave — no scalar load, no wait — so the state loads go out a scalar-memory round trip earlier; in the shipped
+// build (DRONE_EARLY_ARGS=0) they are ordinary, unused kernel arguments (kept: the two builds share one signature).
 #define DRONE_STEP_PRE_PARAMS const float4* __restrict__ pre_planes, const float* __restrict__ pre_act, const uint32_t* __restrict__ pre_ctr, uint32_t pre_n, uint32_t pre_n_pad, \
                               uint32_t pre_order, uint32_t pre_nwg, uint32_t pre_gstep, uint32_t pre_slot
 

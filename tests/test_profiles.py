@@ -1,6 +1,6 @@
-"""profiles/r05_*: what is committed as evidence must be one consistent set (VERDICT r3 item 2b — half of profiles/r03_*
+"""profiles/r06_*: what is committed as evidence must be one consistent set (VERDICT r3 item 2b — half of profiles/r03_*
 named a kernel that no longer existed; round 4's set, profiles/r04_*, stays as history: its summaries name the build it came
-from, whose fused-rollout kernel had one argument fewer). Every round-5 profile directory names the build it measured (git revision, sha256
+from, whose fused-rollout kernel had one argument fewer). Every profile directory of the round names the build it measured (git revision, sha256
 of the libdrone_hip.so that ran on the GPU box) and its kernels by demangled and mangled name; here, on the CPU:
   * the kernel rows of kernel_stats.csv and of summary.json are the same kernels;
   * every mangled name exists in the ISA listing of the CURRENT sources (a kernel renamed or re-templated after the
@@ -18,10 +18,10 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"
+ROUND = "r06"
 DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", ROUND + "_*")) if os.path.isfile(os.path.join(d, "summary.json")))
 
-pytestmark = pytest.mark.skipif(not DIRS, reason="no round-5 profiles committed yet (tools/round_profiles.sh on the GPU box, tools/collect_round.py here)")
+pytestmark = pytest.mark.skipif(not DIRS, reason="no profiles of this round committed yet (tools/round_profiles.sh on the GPU box, tools/collect_round.py here)")
 
 
 @pytest.fixture(scope="module")
@@ -97,11 +97,11 @@ def test_the_bench_lines_roofline_is_reproduced_by_the_profile():
     # the PMC traffic against the algorithmic bytes: no wasted re-reads
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))[f"hover:{rf['envs']}"]
     assert 0.97 < t["hbm_bytes_per_launch"] / (rf["algorithmic_bytes_per_env_step"] * rf["envs"]) < 1.05
-    # the variant strings in the line are instantiations the parity suite covers; beyond 400 MiB per step each process measures its
-    # own sweep order at its first reset (round 5), so the bench process and the profiled one may have picked different ones
+    # the variant strings in the line are the footprint table's entries (round 6: the online measurement is opt-in), and the profiled
+    # kernels are those instantiations (task, compact, MEM, DT, PEER)
     big = line["variants"][f"hover:{rf['envs']}"]
-    assert "dt=1" in big and any(f" order={o} " in big for o in (0, 6, 8)) and "<0, false," in k["name"] and "true>" in k["name"].split("(HIP_vector_type")[0]
-    assert "mem=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, 0, true>" in k2["name"]
+    assert "mem=2,dt=1" in big and " order=8 " in big and "autotuned" not in big and "<0, false, 2, true, false>" in k["name"]
+    assert "mem=0,dt=1" in line["variants"][f"hover:{am['envs']}"] and "<0, false, 0, true, false>" in k2["name"]
     # the driver's 20-step window (--steps 20 --warmup 5 behind the 150-step pre-roll) describes the same kernel state as the
     # profile: its ms_per_step within 2 % of rocprofv3's average at the metric's size
     drv = json.load(open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_driver_window.json")))

@@ -18,7 +18,8 @@ SRC = os.path.join(ROOT, "gpurun_out", "r06_flake")
 DST = os.path.join(ROOT, "profiles", "r06_flake")
 BUILDS = {"A": "as shipped by round 5 (kernarg preload, -DDRONE_EARLY_ARGS=2)", "B": "-DDRONE_EARLY_ARGS=0 without -mllvm -amdgpu-kernarg-preload-count=12",
           "C": "A + profiles/r05_ab/stop_word_withdrawn.patch (round 5's stop word in every instantiation)",
-          "D": "round 6: pruned source, stop word as PEER instantiations only (what ships)", "E": "D without kernarg preloading"}
+          "D": "round 6's source (pruned; stop word as PEER instantiations only) built WITH kernarg preloading",
+          "E": "round 6 as shipped: the same source without kernarg preloading (make default)"}
 
 
 def upper95(fails, n):
