@@ -19,7 +19,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND = "r06"
-DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", ROUND + "_*")) if os.path.isfile(os.path.join(d, "summary.json")))
+DIRS = sorted(d for d in glob.glob(os.path.join(ROOT, "profiles", ROUND + "_*")) if os.path.isfile(os.path.join(d, "summary.json")) and os.path.isfile(os.path.join(d, "kernel_stats.csv")))  # (profiles/r06_flake, r06_pruned: not profile directories)
 
 pytestmark = pytest.mark.skipif(not DIRS, reason="no profiles of this round committed yet (tools/round_profiles.sh on the GPU box, tools/collect_round.py here)")
 
