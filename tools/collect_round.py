@@ -127,7 +127,7 @@ def main():
         per = k["SQ_INSTS_VALU"] / k["SQ_WAVES"] / 128.0
         note = (f"SQ_INSTS_VALU {k['SQ_INSTS_VALU']:.4g} / {k['SQ_WAVES']:.0f} waves / 128 steps (profiles/{ROUND}_rollout_hover/sq_counters.json, build {build.get('git_head', '?')[:12]}); "
                 "issue roof: 1.03 ns per wave64 VALU per SIMD, the best f32 rate measured (v_mul_f32, 8 waves/SIMD; v_fma_f32 1.17-1.22 ns) in profiles/micro_valu_issue.txt")
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rollout_flops.py"), "hover", "drone_rollout_kernelILi0ELb0E", f"{per:.1f}", "1.03", note], check=True)
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rollout_flops.py"), "hover", "drone_rollout_kernelILi0ELb0ELb0EE", f"{per:.1f}", "1.03", note], check=True)
     except (OSError, StopIteration, KeyError) as exc:
         print("rollout_valu.json not refreshed:", exc)
     print("profiles written for:", made)

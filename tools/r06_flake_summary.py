@@ -72,7 +72,13 @@ def main():
             s = suites.setdefault(r["build"], {"runs": 0, "failed": 0, "detail": []})
             s["runs"] += 1
             s["failed"] += failed
-            s["detail"].append({"tag": r["tag"], "rc": r["rc"], "seconds": r["seconds"], "summary": r.get("summary", "")})
+            text = ""
+            try:  # pytest's own summary line (the record's is whatever came last on stdout: RCCL's banner)
+                f = os.path.join(SRC, r["tag"], f"suite_{r['build']}_{r['rep']}.txt")
+                text = next((l.strip(" =") for l in reversed(open(f, errors="replace").read().splitlines()) if re.search(r"\d+ passed|\d+ failed", l)), "")
+            except OSError:
+                pass
+            s["detail"].append({"tag": r["tag"], "rc": r["rc"], "seconds": r["seconds"], "summary": text or r.get("summary", "")})
         else:
             c = cells.setdefault(r["build"], {}).setdefault(r["workload"], {"runs": 0, "failed": 0, "soft": 0, "seconds": 0, "by_box": {}})
             c["runs"] += 1
