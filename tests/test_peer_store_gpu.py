@@ -490,37 +490,26 @@ def test_two_launches_without_a_gather_are_refused(hip, tmp_path):
 
 
 
-_WORKER_VMM = r"""
-import sys
-sys.path.insert(0, {root!r})
-import torch
-from drone_amd import binding
-dev = torch.device("cuda:0")
-v = binding.DroneVec(1024, seed=1, task=0, device=dev)
-g = (torch.zeros((1024, 20), dtype=torch.float32, device=dev), torch.zeros(1024, dtype=torch.float32, device=dev),
-     torch.zeros(1024, dtype=torch.uint8, device=dev), torch.zeros(1024, dtype=torch.uint8, device=dev))
-try:
-    v.gather_peer_export(*g)
-    print("EXPORTED", flush=True)
-except RuntimeError as exc:
-    print("ERROR", str(exc), flush=True)
-"""
-
-
 def test_export_of_a_virtual_memory_allocation_names_the_way_out(hip, tmp_path):
-    """hipIpcGetMemHandle has no handle for a virtual-memory mapping (hipMemCreate / hipMemMap) — which is what
-    torch hands out under PYTORCH_HIP_ALLOC_CONF=expandable_segments:True. drone_vec_gather_peer_export must then say what to do
-    (drone_device_malloc) instead of relaying "invalid argument". Where this torch build's allocator does not use such mappings the
-    export simply works and there is nothing to check."""
-    script = tmp_path / "worker_vmm.py"
-    script.write_text(_WORKER_VMM.format(root=ROOT))
-    env = dict(os.environ, PYTORCH_HIP_ALLOC_CONF="expandable_segments:True", PYTORCH_CUDA_ALLOC_CONF="expandable_segments:True", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
-    if "EXPORTED" in r.stdout:
-        pytest.skip("this torch build's allocator hands out plain allocations even with expandable_segments:True: the export works")
-    line = next(l for l in r.stdout.splitlines() if l.startswith("ERROR"))
-    assert "drone_device_malloc" in line and "hipIpcGetMemHandle" in line and "virtual-memory" in line, line
+    """hipIpcGetMemHandle has no handle for a virtual-memory mapping (hipMemCreate / hipMemAddressReserve /
+    hipMemMap — what an expandable-segments allocator hands out). drone_vec_gather_peer_export must then say what to do
+    (drone_device_malloc) instead of relaying "invalid argument". tests/c/vmm_export_probe.c builds such a mapping with the HIP
+    virtual-memory API, places the four global buffers in it and exports them; the same export from drone_device_malloc
+    buffers is the positive control. (This torch build's allocator hands out plain allocations even under
+    expandable_segments:True, so the probe is plain C.)"""
+    exe = str(tmp_path / "vmm_export_probe")
+    subprocess.run(["gcc", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "vmm_export_probe.c"),
+                    "-L" + os.path.join(ROOT, "drone_amd"), "-l:libdrone_hip.so", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "drone_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = dict(l.split(" ", 1) for l in r.stdout.splitlines() if l.split(" ", 1)[0] in ("PLAIN", "VMM", "VMM_UNAVAILABLE"))
+    assert lines["PLAIN"].startswith("rc=0"), r.stdout
+    if "VMM_UNAVAILABLE" in lines:
+        pytest.skip("this runtime has no virtual-memory API: " + lines["VMM_UNAVAILABLE"])
+    if lines["VMM"].startswith("rc=0"):
+        pytest.skip("this runtime gives a virtual-memory mapping an IPC handle: the export works")
+    assert "drone_device_malloc" in lines["VMM"] and "hipIpcGetMemHandle" in lines["VMM"] and "virtual-memory" in lines["VMM"], lines["VMM"]
 
 
 @pytest.mark.parametrize("world,rollout", [(2, 0), (3, 16)])
