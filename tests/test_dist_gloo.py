@@ -191,3 +191,70 @@ def test_shard_range_covers_everything():
             assert spans[-1][0] + spans[-1][1] == total
             assert sum(shard_counts(total, world)) == total
     assert shard_range(1 << 20, 3, 8) == (3 * 131072, 131072)
+
+
+class _FakePeerVec:
+    """The surface PeerStoreGather's CONSTRUCTOR touches, without a GPU: what is under test is its own choreography — the
+    export on the root, the token and the page's name over torch.distributed, every rank learning whether all could join."""
+
+    class _Cfg:
+        task = 0
+
+    def __init__(self, rank, fail_rank):
+        self.torch_device, self.cfg, self.rank, self.fail_rank = torch.device("cpu"), self._Cfg(), rank, fail_rank
+        self.closed = False
+
+    def gather_peer_export(self, obs, rew, term, trunc):
+        return bytes(288)
+
+    def gather_init_peer(self, token, flags, rank, world, root=0, counts=None):
+        assert len(token) == 288 and flags.shape == (1024,)
+        if rank == self.fail_rank:
+            raise RuntimeError(f"rank {rank} could not map the root's batch (injected)")
+
+    def gather_close(self):
+        self.closed = True
+
+
+def _peer_ctor_worker(rank, world, port, fail_rank, q):
+    import time
+
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drone_amd.dist import PeerStoreGather
+
+    v, t0, err = _FakePeerVec(rank, fail_rank), time.time(), None
+    try:
+        PeerStoreGather(v, 64 * world, root=0)
+    except RuntimeError as exc:
+        err = str(exc)
+    q.put((rank, err, v.closed, time.time() - t0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_peer_store_gather_constructor_fails_on_every_rank_together(fail_rank):
+    """a rank that could not join the exchange (memmap, IPC open) used to skip the barrier the others then sat in until
+    the process-group timeout. Now every rank learns, in ONE collective that also serves as that barrier, whether all could
+    join: either all return, or all raise at once — the ranks that had joined undo it — and the flag page's name is gone either way."""
+    world = 2
+    before = {f for f in os.listdir("/dev/shm") if f.startswith("drone_peer_flags_")}
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29900 + (os.getpid() % 1500) + fail_rank + 2
+    procs = [ctx.Process(target=_peer_ctor_worker, args=(r, world, port, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get() for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if fail_rank < 0:
+        assert all(err is None and not closed for _, err, closed, _ in got), got
+    else:
+        assert "injected" in got[1][1] and "could not join" in got[0][1] and got[0][2], got  # the healthy rank undid its join
+    assert all(took < 30 for *_, took in got), got
+    assert {f for f in os.listdir("/dev/shm") if f.startswith("drone_peer_flags_")} == before
