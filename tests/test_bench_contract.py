@@ -168,6 +168,10 @@ def test_workload_argv():
         "--steps=20", "--task", "race", "--total-envs=4096"]
     assert bench.workload_argv(["--phase", "core", "--optional-timeout", "45", "--seed", "7", "--no-extras", "--ring", "2"]) == ["--seed", "7", "--ring", "2"]
     assert bench.workload_argv([]) == []
+    # every record a preflight item can gate is an optional record of the line (a renamed record must not silently lose its gate)
+    gated = {name for names in bench.PREFLIGHT_GATES.values() for name in names}
+    assert gated <= OPTIONAL | {"gather_step_cabi", "rollout_gather_overlap"}, gated - OPTIONAL
+    assert set(bench.PREFLIGHT_GATES) <= PREFLIGHT_ITEMS
     # every handle bench.py says it times is listed once
     assert len({(t, n) for t, n, _ in bench.TIMED_HANDLES}) == len(bench.TIMED_HANDLES)
 
